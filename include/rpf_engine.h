@@ -1,0 +1,129 @@
+/*
+ * rpf_engine.h -- C-ABI of the MI355X power-spectrum engine.
+ *
+ * This is the drop-in boundary for the FFT-and-accumulate worker of
+ * rtl_power_fftw: everything `class Datastore` exposes to its two callers
+ * (/root/reference/src/datastore.h:35-68, used from
+ * /root/reference/src/acquisition.cxx:252-256,278-324,343-347,377-397 and
+ * /root/reference/src/rtl_power_fftw.cxx:112,169,215), flattened to
+ * `extern "C"` functions on an opaque handle, plain pointers and sizes.
+ * No exceptions cross it; every call returns an int that is either RPF_OK or
+ * one of the reference's own process exit codes
+ * (/root/reference/src/exceptions.h:25-34), so the host turns a failure into
+ * `throw RPFexception(rpf_last_error(e), (ReturnValue)rc)` unchanged.
+ *
+ * Threading contract (same as the reference, datastore.h:40-47): exactly one
+ * producer thread calls begin/acquire/submit/unget/finish; the engine owns its
+ * consumer thread and its HIP streams; rpf_get_* are valid after rpf_finish.
+ *
+ * The implementation (rtl-power-fftw_amd/csrc) is hand-written HIP for gfx950.
+ * There is no CPU fallback: without a usable HIP device rpf_engine_create
+ * fails with RPF_ERR_HARDWARE.
+ */
+#ifndef RPF_ENGINE_H
+#define RPF_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPF_ABI_VERSION 1
+
+/* Return codes = ReturnValue of /root/reference/src/exceptions.h:25-34. */
+#define RPF_OK 0
+#define RPF_ERR_INVALID_ARGUMENT 3 /* ReturnValue::InvalidArgument */
+#define RPF_ERR_INVALID_INPUT 5    /* ReturnValue::InvalidInput    */
+#define RPF_ERR_ACQUISITION 6      /* ReturnValue::AcquisitionError */
+#define RPF_ERR_HARDWARE 7         /* ReturnValue::HardwareError   */
+
+typedef struct rpf_engine rpf_engine;
+
+/* Mirrors the Params fields Datastore reads (datastore.cxx:23-34,67-76):
+ * N, buffers, buf_length, window (+ the window values of AuxData). */
+typedef struct rpf_config {
+    uint32_t struct_size;     /* = sizeof(rpf_config), for ABI evolution          */
+    int32_t N;                /* params.N: FFT bins, even (params.cxx:150-155)    */
+    const float* window;      /* params.window ? N floats (copied) : NULL         */
+    int32_t n_buffers;        /* params.buffers (default 5, params.h:42)          */
+    int64_t buffer_capacity;  /* params.buf_length in bytes (params.h:43)         */
+    int32_t device;           /* HIP device ordinal                               */
+    uint32_t flags;           /* RPF_FLAG_*                                       */
+} rpf_config;
+
+#define RPF_FLAG_NONE 0u
+/* Stage raw bytes through VGPRs instead of LDS-DMA (debug / A-B measurement). */
+#define RPF_FLAG_NO_LDS_DMA 1u
+
+/* ABI version of the loaded library. */
+int rpf_abi_version(void);
+/* 1 if this build has a gfx950 kernel for N bins, else 0 (the supported set is
+ * listed in DESIGN.md; an unsupported N makes rpf_engine_create fail with
+ * RPF_ERR_INVALID_ARGUMENT rather than fall back to anything). */
+int rpf_supported_n(int N);
+/* Message of the last failure on this thread when no engine exists yet. */
+const char* rpf_last_global_error(void);
+
+/* Datastore::Datastore (datastore.cxx:23-34): buffer pool (pinned host memory
+ * the producer fills directly), FFT plan (= twiddle tables on the device),
+ * zeroed pwr[N] and queue_histogram[n_buffers+1]. */
+int rpf_engine_create(const rpf_config* cfg, rpf_engine** out);
+/* Datastore::~Datastore (datastore.cxx:36-46). */
+void rpf_engine_destroy(rpf_engine* e);
+const char* rpf_last_error(const rpf_engine* e);
+
+/* Start of Acquisition::run's worker section (acquisition.cxx:252-256):
+ * pwr := 0, acquisition_finished := false, repeats_done := 0, start the
+ * consumer.  `repeats` = params.repeats for this acquisition. */
+int rpf_begin(rpf_engine* e, int64_t repeats);
+
+/* acquisition.cxx:278-285: samples queue_histogram[#empty] and then blocks
+ * until a buffer is free; returns it with its capacity. */
+int rpf_buffer_acquire(rpf_engine* e, uint8_t** buf, size_t* capacity);
+/* acquisition.cxx:302,320-323: buffer.resize(nbytes) + push_back to
+ * occupied_buffers + notify.  nbytes even, <= capacity. */
+int rpf_buffer_submit(rpf_engine* e, uint8_t* buf, size_t nbytes);
+/* acquisition.cxx:310-314: failed readout, buffer goes back to the FRONT of
+ * empty_buffers. */
+int rpf_buffer_unget(rpf_engine* e, uint8_t* buf);
+
+/* acquisition.cxx:343-347: acquisition_finished := true, notify, join.  On
+ * return every submitted byte has been consumed per datastore.cxx:67-89
+ * (frames may straddle buffers; frames beyond `repeats` and a trailing partial
+ * frame are dropped) and pwr/repeats_done are final. */
+int rpf_finish(rpf_engine* e, int64_t* repeats_done);
+
+/* Datastore::pwr (datastore.h:53) -- raw accumulated |X|^2 per bin, bin N/2 =
+ * DC; the DC interpolation of acquisition.cxx:377 is the caller's.  */
+int rpf_get_power(const rpf_engine* e, double* out /* N */);
+/* Datastore::repeats_done (datastore.h:38). */
+int64_t rpf_get_repeats_done(const rpf_engine* e);
+/* Datastore::queue_histogram (datastore.h:47), cumulative over the engine's
+ * life like the reference's (never reset, datastore.cxx:24). */
+int rpf_get_histogram(const rpf_engine* e, int* out /* n_buffers + 1 */);
+
+/* Whole acquisition on one contiguous host stream, driven through the same
+ * begin/acquire/submit/finish path in buffer_capacity-sized pieces. */
+int rpf_accumulate(rpf_engine* e, const uint8_t* stream, size_t nbytes, int64_t repeats,
+                   double* pwr_out /* N, host */, int64_t* repeats_done);
+
+/* Device-resident replay: the stream already sits in HBM (d_stream, 16-byte
+ * aligned).  Enqueues the fused kernel and the partial-sum reduce on
+ * `hip_stream` (a hipStream_t, NULL = the engine's own stream) and returns
+ * without synchronising; d_pwr_out[N] (device doubles) is overwritten with the
+ * sum over frames [0, min(repeats, nbytes/(2N))).  Used by bench.py and the
+ * full-size parity tests; does not touch the buffer queues. */
+int rpf_accumulate_device(rpf_engine* e, const void* d_stream, size_t nbytes, int64_t repeats,
+                          double* d_pwr_out, void* hip_stream, int64_t* repeats_done);
+
+/* Launch geometry of the last fused-kernel launch (for DESIGN/bench reporting):
+ * workgroups, threads per workgroup, frames per workgroup, LDS bytes. */
+int rpf_last_launch_info(const rpf_engine* e, int* grid, int* block, int* frames_per_wg,
+                         int* lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPF_ENGINE_H */

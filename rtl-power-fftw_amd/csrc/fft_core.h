@@ -1,0 +1,307 @@
+// fft_core.h -- per-thread building blocks of the fused
+//   u8-IQ unpack -> (-1)^n centring -> window -> FFT -> |X|^2 accumulate
+// kernel (rpf_kernels.hip).  Everything here is plain C++17 on registers and
+// pointers so that the same code is compiled (a) by hipcc into the gfx950 kernel
+// and (b) by g++ into the thread-by-thread emulator under tests/ that checks
+// the index maps on a machine without a GPU.  There is no CPU product path.
+//
+// What is computed (reference: /root/reference/src/datastore.cxx:66-89):
+//   x[n]  = ((float)I_n - 127, (float)Q_n - 127) * (-1)^n [* window[n]]   (:73-77)
+//   X[k]  = sum_n x[n] exp(-2 pi i n k / N)                              (:82)
+//   pwr[k] += (double)Re^2 + (double)Im^2                                 (:83-85)
+//
+// Algorithm: decimation-in-frequency FFT, N = P^(NPASS-1) * RLAST, executed by
+// T = N/P threads that each hold P complex points in registers.  Passes
+// 1..NPASS-1 are radix-P butterflies on elements L_j apart followed by the
+// twiddle W_{L_{j-1}}^{m r}; the last pass is P/RLAST radix-RLAST butterflies
+// on consecutive elements.  The transform is done "in place" by element name
+// e in [0,N): a pass never renames elements, only the LDS exchanges between
+// passes move them between threads.  The result is therefore left in
+// digit-reversed order, which costs nothing here because the only consumer is
+// a per-bin accumulator that lives wherever its bin lands (bin_of()).
+#pragma once
+
+#include <cstdint>
+#include <type_traits>
+
+#if defined(__HIPCC__)
+#define RPF_HD __host__ __device__ __forceinline__
+#else
+#define RPF_HD inline __attribute__((always_inline))
+#endif
+
+namespace rpf {
+
+struct cf {
+    float x, y;
+};
+
+RPF_HD cf operator+(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
+RPF_HD cf operator-(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
+RPF_HD cf cmul(cf a, cf w) { return {a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
+// multiply by -i
+RPF_HD cf mul_mi(cf a) { return {a.y, -a.x}; }
+
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
+
+// ---------------------------------------------------------------- geometry --
+template <int N_, int P_>
+struct Geom {
+    static constexpr int N = N_;
+    static constexpr int P = P_;                       // points per thread
+    static constexpr int T = N / P;                    // threads per frame
+    static constexpr int LOG2N = ilog2(N);
+    static constexpr int LOG2P = ilog2(P);
+    static constexpr int NPASS = (LOG2N + LOG2P - 1) / LOG2P;
+    static constexpr int RLAST = N / ipow(P, NPASS - 1);   // radix of the last pass
+    static constexpr int LDS_CPX = N + N / P;           // padded complex slots per frame
+    static_assert((1 << LOG2N) == N && (1 << LOG2P) == P, "N and P must be powers of two");
+    static_assert(NPASS >= 2, "need at least two passes (N > P)");
+    static_assert(T % 2 == 0, "T must be even so that (-1)^n is a per-thread constant");
+    static_assert(P % 8 == 0, "a thread stages 2P raw bytes in 16-byte pieces");
+
+    // sub-FFT length entering pass J (1-based): L_{J-1}
+    static constexpr int Lprev(int J) { return N / ipow(P, J - 1); }
+    // distance between the P inputs of a pass-J butterfly: L_J
+    static constexpr int Lcur(int J) { return Lprev(J) / P; }
+    // padded LDS slot of element e: one spare slot after every P elements keeps
+    // every access pattern used below free of bank conflicts.
+    static RPF_HD int slot(int e) { return e + (e >> LOG2P); }
+};
+
+// element held in register a by thread t during pass J
+template <class G, int J>
+RPF_HD int elem_of(int t, int a)
+{
+    if constexpr (J < G::NPASS) {
+        constexpr int Lp = G::Lprev(J), Lc = G::Lcur(J);
+        const int s = t / Lc, m = t % Lc;
+        return s * Lp + m + Lc * a;
+    } else {
+        return G::P * t + a;
+    }
+}
+
+// Spectrum bin of the value that ends the last pass in register a of thread t.
+// Element e = sum_j d_j L_j (digits d_1..d_{NPASS-1} in [0,P), last digit in
+// [0,RLAST)) holds X[d_1 + P d_2 + P^2 d_3 + ...].
+template <class G>
+RPF_HD int bin_of(int t, int a)
+{
+    int e = G::P * t + a;
+    int bin = 0, weight = 1;
+    // digits from the most significant (d_1, weight 1) down
+    for (int j = 1; j < G::NPASS; ++j) {
+        const int L = G::N / ipow(G::P, j);     // L_j
+        const int d = e / L;
+        e -= d * L;
+        bin += d * weight;
+        weight *= G::P;
+    }
+    return bin + e * weight;
+}
+
+// ------------------------------------------------------- constant twiddles --
+// W_16^k for k in [0,16): (cos, -sin) of k/16 turn, correctly rounded floats.
+constexpr float kC1 = 0.92387953251128673848f;   // cos(pi/8)
+constexpr float kS1 = 0.38268343236508978178f;   // sin(pi/8)
+constexpr float kH = 0.70710678118654752440f;    // sqrt(1/2)
+
+template <int K16>   // multiply by W_16^{K16}
+RPF_HD cf mul_w16(cf a)
+{
+    constexpr int k = ((K16 % 16) + 16) % 16;
+    if constexpr (k == 0) return a;
+    else if constexpr (k == 4) return mul_mi(a);
+    else if constexpr (k == 8) return {-a.x, -a.y};
+    else if constexpr (k == 12) return {-a.y, a.x};
+    else if constexpr (k == 2) return {(a.x + a.y) * kH, (a.y - a.x) * kH};
+    else if constexpr (k == 6) return {(a.y - a.x) * kH, -(a.x + a.y) * kH};
+    else if constexpr (k == 10) return {-(a.x + a.y) * kH, (a.x - a.y) * kH};
+    else if constexpr (k == 14) return {(a.x - a.y) * kH, (a.x + a.y) * kH};
+    else {
+        // odd k: (c, -s) with c,s from {C1,S1} and signs by quadrant
+        constexpr float c = (k == 1 || k == 15) ? kC1 : (k == 3 || k == 13) ? kS1
+                          : (k == 5 || k == 11) ? -kS1 : -kC1;            // cos(2 pi k/16)
+        constexpr float s = (k == 1 || k == 7) ? kS1 : (k == 3 || k == 5) ? kC1
+                          : (k == 9 || k == 15) ? -kS1 : -kC1;            // sin(2 pi k/16)
+        return {a.x * c + a.y * s, a.y * c - a.x * s};                    // a * (c - i s)
+    }
+}
+
+// ----------------------------------------------------- in-register DFTs --
+// dft<R>(v): v[r] <- sum_a v[a] W_R^{a r}, natural order in, natural order out.
+template <int R>
+struct Dft;
+
+template <>
+struct Dft<2> {
+    static RPF_HD void run(cf* v)
+    {
+        const cf a = v[0], b = v[1];
+        v[0] = a + b;
+        v[1] = a - b;
+    }
+};
+
+template <>
+struct Dft<4> {
+    static RPF_HD void run(cf* v)
+    {
+        const cf apc = v[0] + v[2], amc = v[0] - v[2];
+        const cf bpd = v[1] + v[3], jbmd = mul_mi(v[1] - v[3]);
+        v[0] = apc + bpd;
+        v[1] = amc + jbmd;
+        v[2] = apc - bpd;
+        v[3] = amc - jbmd;
+    }
+};
+
+// R = R1*R2 by one Cooley-Tukey step: a = a0 + R1 a1, r = r0 + R2 r1.
+template <int R, int R1, int R2>
+struct DftCompose {
+    static RPF_HD void run(cf* v)
+    {
+        static_assert(R == R1 * R2 && 16 % R == 0, "");
+        cf col[R2];
+#pragma unroll
+        for (int a0 = 0; a0 < R1; ++a0) {
+#pragma unroll
+            for (int a1 = 0; a1 < R2; ++a1) col[a1] = v[a0 + R1 * a1];
+            Dft<R2>::run(col);
+#pragma unroll
+            for (int r0 = 0; r0 < R2; ++r0) v[a0 + R1 * r0] = col[r0];
+        }
+        twiddle_rows(v, std::integral_constant<int, 0>{});
+        cf out[R];
+        cf row[R1];
+#pragma unroll
+        for (int r0 = 0; r0 < R2; ++r0) {
+#pragma unroll
+            for (int a0 = 0; a0 < R1; ++a0) row[a0] = v[a0 + R1 * r0];
+            Dft<R1>::run(row);
+#pragma unroll
+            for (int r1 = 0; r1 < R1; ++r1) out[r0 + R2 * r1] = row[r1];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = out[r];
+    }
+
+    // v[a0 + R1 r0] *= W_R^{a0 r0}; compile-time recursion over idx = a0 + R1 r0
+    template <int IDX>
+    static RPF_HD void twiddle_rows(cf* v, std::integral_constant<int, IDX>)
+    {
+        if constexpr (IDX < R) {
+            constexpr int a0 = IDX % R1, r0 = IDX / R1;
+            v[IDX] = mul_w16<(a0 * r0) * (16 / R)>(v[IDX]);
+            twiddle_rows(v, std::integral_constant<int, IDX + 1>{});
+        }
+    }
+};
+
+template <>
+struct Dft<8> {
+    static RPF_HD void run(cf* v) { DftCompose<8, 2, 4>::run(v); }
+};
+template <>
+struct Dft<16> {
+    static RPF_HD void run(cf* v) { DftCompose<16, 4, 4>::run(v); }
+};
+
+// ------------------------------------------------------------------ phases --
+// Unpack P samples of one frame for pass 1 (datastore.cxx:73-77).  `raw` points
+// at the frame's 2N interleaved bytes.  sgn = (-1)^t (n = t + T a and T is even).
+// wsgn: per-register window values already multiplied by sgn, or nullptr.
+template <class G, bool WINDOW>
+RPF_HD void phase_unpack(int t, const uint8_t* raw, float sgn, const float* wsgn, cf* x)
+{
+    const float off = -127.0f * sgn;
+#pragma unroll
+    for (int a = 0; a < G::P; ++a) {
+        const int n = t + G::T * a;
+        const uint16_t iq = *reinterpret_cast<const uint16_t*>(raw + 2 * n);
+        const float fi = static_cast<float>(iq & 0xffu);
+        const float fq = static_cast<float>(iq >> 8);
+        if constexpr (WINDOW) {
+            // (v - 127) is exact, * (+-w) rounds once: same value as the reference
+            x[a].x = (fi - 127.0f) * wsgn[a];
+            x[a].y = (fq - 127.0f) * wsgn[a];
+        } else {
+            // v*sgn - 127*sgn, exact in float
+            x[a].x = fi * sgn + off;
+            x[a].y = fq * sgn + off;
+        }
+    }
+}
+
+// Radix-P butterfly of a middle pass followed by its twiddles tw[r-1] =
+// W_{L_{J-1}}^{m r}, r = 1..P-1 (m = t mod L_J; loaded once per thread).
+template <class G>
+RPF_HD void phase_butterfly_twiddle(cf* x, const cf* tw)
+{
+    Dft<G::P>::run(x);
+#pragma unroll
+    for (int r = 1; r < G::P; ++r) x[r] = cmul(x[r], tw[r - 1]);
+}
+
+// Last pass: P/RLAST radix-RLAST butterflies on consecutive registers.
+template <class G>
+RPF_HD void phase_last(cf* x)
+{
+#pragma unroll
+    for (int g = 0; g < G::P / G::RLAST; ++g) Dft<G::RLAST>::run(x + g * G::RLAST);
+}
+
+// LDS exchange: registers of pass J <-> padded per-frame slab.  The slot of
+// register a is slot_base<J>(t) + slot_delta<J>(a): a per-thread, loop-invariant
+// base plus a compile-time constant that folds into the DS instruction's
+// immediate offset.  (slot(b + Lc a) = slot(b) + Lc a + floor(Lc a / P) holds
+// because Lc a is a multiple of P when Lc >= P, and m < Lc | P otherwise.)
+template <class G, int J>
+RPF_HD int slot_base(int t)
+{
+    return G::slot(elem_of<G, J>(t, 0));
+}
+template <class G, int J>
+constexpr int slot_delta(int a)
+{
+    if constexpr (J < G::NPASS) return G::Lcur(J) * a + (G::Lcur(J) * a) / G::P;
+    else return a;
+}
+template <class G, int J>
+RPF_HD void phase_store(int t, const cf* x, cf* slab)
+{
+    cf* const p = slab + slot_base<G, J>(t);
+#pragma unroll
+    for (int a = 0; a < G::P; ++a) p[slot_delta<G, J>(a)] = x[a];
+}
+template <class G, int J>
+RPF_HD void phase_fetch(int t, cf* x, const cf* slab)
+{
+    const cf* const p = slab + slot_base<G, J>(t);
+#pragma unroll
+    for (int a = 0; a < G::P; ++a) x[a] = p[slot_delta<G, J>(a)];
+}
+
+// |X|^2 in double, as the reference's pow(float,2)+pow(float,2) (datastore.cxx:84).
+RPF_HD void phase_accumulate(const cf* x, double* acc, int P)
+{
+#pragma unroll
+    for (int a = 0; a < P; ++a) {
+        const double re = static_cast<double>(x[a].x);
+        const double im = static_cast<double>(x[a].y);
+        acc[a] += re * re + im * im;
+    }
+}
+
+// Index into the master twiddle table W_N^k (k in [0,N)) of the pass-J twiddle
+// W_{L_{J-1}}^{m r}:  k = m * r * P^(J-1).
+template <class G, int J>
+RPF_HD int twiddle_index(int t, int r)
+{
+    constexpr int Lc = G::Lcur(J);
+    return (t % Lc) * r * ipow(G::P, J - 1);
+}
+
+}  // namespace rpf

@@ -1,0 +1,537 @@
+// rpf_engine.cpp -- implementation of include/rpf_engine.h: the buffer pool and
+// consumer thread of Datastore (/root/reference/src/datastore.cxx:23-103)
+// re-designed around a HIP device.
+//
+//   producer (caller's thread)                consumer (engine thread)
+//   --------------------------                ------------------------
+//   rpf_buffer_acquire  <-- empty_  <---------  recycle after H2D copy done
+//   fill pinned buffer
+//   rpf_buffer_submit   --> occupied_ ------->  pop, hipMemcpyAsync H2D (copy stream)
+//                                               into a device staging slot placed so
+//                                               that it continues the byte stream of
+//                                               the previous slot's unfinished frame,
+//                                               fused kernel + reduce (compute stream)
+//   rpf_finish          --> finished_ ------->  drain, sync, pwr -> host, exit
+//
+// Pinned host buffers let the H2D copy of buffer k+1 overlap the kernel of
+// buffer k (two streams + events); a frame that straddles two buffers
+// (datastore.cxx:52,68,81) is completed by copying the tail of the previous
+// staging slot in front of the new bytes, device to device.
+#include "../../include/rpf_engine.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "rpf_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct HostBuffer {
+    uint8_t* data = nullptr;
+    size_t size = 0;   // bytes valid after submit (Buffer::size())
+};
+
+struct StagingSlot {
+    uint8_t* base = nullptr;        // device memory: [head_room | buffer_capacity]
+    hipEvent_t kernel_done = nullptr;
+    bool in_flight = false;
+};
+
+}  // namespace
+
+struct rpf_engine {
+    // configuration (Params fields Datastore reads)
+    int N = 0;
+    bool has_window = false;
+    int n_buffers = 0;
+    size_t buffer_capacity = 0;
+    int device = 0;
+    uint32_t flags = 0;
+    bool use_dma = true;
+
+    // Datastore public state
+    int64_t repeats = 0;        // params.repeats of the running acquisition
+    int64_t repeats_done = 0;   // datastore.h:38
+    std::mutex status_mutex;    // datastore.h:40
+    std::deque<HostBuffer*> empty_buffers;      // :43
+    std::deque<HostBuffer*> occupied_buffers;   // :44
+    bool acquisition_finished = false;          // :45
+    std::condition_variable status_change;      // :46
+    std::vector<int> queue_histogram;           // :47
+    std::vector<double> pwr;                    // :53
+
+    std::vector<HostBuffer> pool;
+    std::thread worker;
+    bool worker_running = false;
+    int worker_rc = RPF_OK;
+    std::string worker_error;
+
+    // device side
+    hipStream_t copy_stream = nullptr, compute_stream = nullptr;
+    rpf::cf* d_twiddles = nullptr;
+    float* d_window = nullptr;
+    double* d_partial = nullptr;
+    double* d_pwr = nullptr;
+    size_t head_room = 0;                 // >= 2N, multiple of 256
+    std::vector<StagingSlot> staging;
+    hipEvent_t copy_done = nullptr;
+    rpf::LaunchInfo plan;                 // resident grid for this N
+    rpf::LaunchInfo last;                 // last launch
+
+    mutable std::string last_error;
+};
+
+namespace {
+
+int fail(rpf_engine* e, int rc, const std::string& msg)
+{
+    if (e) e->last_error = msg;
+    g_last_error = msg;
+    return rc;
+}
+
+#define HIP_TRY(e, call)                                                                 \
+    do {                                                                                 \
+        hipError_t err__ = (call);                                                       \
+        if (err__ != hipSuccess)                                                         \
+            return fail(e, RPF_ERR_HARDWARE,                                             \
+                        std::string(#call) + ": " + hipGetErrorString(err__));           \
+    } while (0)
+
+// Launch the fused kernel + reduce for `nframes` frames starting at d_frames.
+int launch_frames(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, double* d_out,
+                  bool accumulate, hipStream_t stream)
+{
+    if (nframes <= 0) return RPF_OK;
+    const bool aligned = (reinterpret_cast<uintptr_t>(d_frames) % 16) == 0;
+    const bool dma = e->use_dma && aligned;
+    const int64_t wanted = (nframes + e->plan.fpw - 1) / e->plan.fpw;
+    const int grid = static_cast<int>(std::min<int64_t>(e->plan.grid, wanted));
+    HIP_TRY(e, rpf::launch_fft_accum(e->N, e->has_window, dma, d_frames, nframes, e->d_twiddles,
+                                     e->d_window, e->d_partial, grid, stream, &e->last));
+    HIP_TRY(e, rpf::launch_reduce(e->d_partial, grid * e->plan.fpw, e->N, d_out, accumulate,
+                                  stream));
+    return RPF_OK;
+}
+
+// Consumer thread: the GPU counterpart of Datastore::fftThread.
+void worker_main(rpf_engine* e)
+{
+    auto bail = [&](hipError_t err, const char* what) {
+        e->worker_rc = RPF_ERR_HARDWARE;
+        e->worker_error = std::string(what) + ": " + hipGetErrorString(err);
+    };
+    hipError_t err = hipSetDevice(e->device);
+    if (err != hipSuccess) bail(err, "hipSetDevice");
+
+    const size_t frame_bytes = 2 * static_cast<size_t>(e->N);
+    size_t carry = 0;             // bytes of an unfinished frame at the end of the previous slot
+    const uint8_t* carry_src = nullptr;
+    size_t slot_idx = 0;
+    int64_t frames_issued = 0;    // == repeats_done once everything has drained
+
+    std::unique_lock<std::mutex> status_lock(e->status_mutex, std::defer_lock);
+    while (true) {
+        // Wait until we have a bufferful of data (datastore.cxx:54-64)
+        status_lock.lock();
+        while (e->occupied_buffers.empty() && !e->acquisition_finished)
+            e->status_change.wait(status_lock);
+        if (e->occupied_buffers.empty()) {
+            status_lock.unlock();
+            break;   // acquisition finished
+        }
+        HostBuffer* buffer = e->occupied_buffers.front();
+        e->occupied_buffers.pop_front();
+        status_lock.unlock();
+
+        // datastore.cxx:67: once the quota is met the rest of the stream is ignored
+        if (e->worker_rc == RPF_OK && frames_issued < e->repeats && buffer->size > 0) {
+            StagingSlot& slot = e->staging[slot_idx];
+            slot_idx = (slot_idx + 1) % e->staging.size();
+            // The slot is free once its own kernel AND the next buffer's carry copy
+            // (which read its tail) are done; the latter precedes the next slot's
+            // kernel_done in stream order.
+            StagingSlot& after = e->staging[slot_idx];
+            for (StagingSlot* s : {&slot, &after}) {
+                if (!s->in_flight) continue;
+                err = hipEventSynchronize(s->kernel_done);
+                if (err != hipSuccess) bail(err, "hipEventSynchronize(kernel_done)");
+                s->in_flight = false;
+            }
+            // new bytes go right after the head room; the carried partial frame
+            // is placed immediately in front of them
+            uint8_t* dst = slot.base + e->head_room;
+            err = hipMemcpyAsync(dst, buffer->data, buffer->size, hipMemcpyHostToDevice,
+                                 e->copy_stream);
+            if (err != hipSuccess) bail(err, "hipMemcpyAsync(H2D)");
+            err = hipEventRecord(e->copy_done, e->copy_stream);
+            if (err != hipSuccess) bail(err, "hipEventRecord(copy_done)");
+            if (carry) {
+                err = hipMemcpyAsync(dst - carry, carry_src, carry, hipMemcpyDeviceToDevice,
+                                     e->compute_stream);
+                if (err != hipSuccess) bail(err, "hipMemcpyAsync(carry)");
+            }
+            err = hipStreamWaitEvent(e->compute_stream, e->copy_done, 0);
+            if (err != hipSuccess) bail(err, "hipStreamWaitEvent");
+
+            const size_t avail = carry + buffer->size;
+            int64_t nframes = static_cast<int64_t>(avail / frame_bytes);
+            nframes = std::min<int64_t>(nframes, e->repeats - frames_issued);
+            if (e->worker_rc == RPF_OK && nframes > 0) {
+                int rc = launch_frames(e, dst - carry, nframes, e->d_pwr, /*accumulate=*/true,
+                                       e->compute_stream);
+                if (rc != RPF_OK) {
+                    e->worker_rc = rc;
+                    e->worker_error = e->last_error;
+                }
+                frames_issued += nframes;
+            }
+            err = hipEventRecord(slot.kernel_done, e->compute_stream);
+            if (err != hipSuccess) bail(err, "hipEventRecord(kernel_done)");
+            slot.in_flight = true;
+            // the unfinished frame (if any) stays in this slot until the next buffer
+            const size_t consumed = static_cast<size_t>(nframes) * frame_bytes;
+            carry = (frames_issued < e->repeats) ? (avail - consumed) % frame_bytes : 0;
+            carry_src = dst + buffer->size - carry;
+            // the pinned buffer may be refilled as soon as its H2D copy is done
+            err = hipEventSynchronize(e->copy_done);
+            if (err != hipSuccess) bail(err, "hipEventSynchronize(copy_done)");
+        }
+
+        // datastore.cxx:91-94
+        status_lock.lock();
+        e->empty_buffers.push_back(buffer);
+        e->status_change.notify_all();
+        status_lock.unlock();
+    }
+
+    err = hipStreamSynchronize(e->compute_stream);
+    if (err != hipSuccess) bail(err, "hipStreamSynchronize");
+    for (auto& s : e->staging) s.in_flight = false;
+    if (e->worker_rc == RPF_OK) {
+        err = hipMemcpy(e->pwr.data(), e->d_pwr, sizeof(double) * e->N, hipMemcpyDeviceToHost);
+        if (err != hipSuccess) bail(err, "hipMemcpy(pwr)");
+    }
+    e->repeats_done = frames_issued;
+}
+
+void release_device(rpf_engine* e)
+{
+    if (e->d_twiddles) (void)hipFree(e->d_twiddles);
+    if (e->d_window) (void)hipFree(e->d_window);
+    if (e->d_partial) (void)hipFree(e->d_partial);
+    if (e->d_pwr) (void)hipFree(e->d_pwr);
+    for (auto& s : e->staging) {
+        if (s.base) (void)hipFree(s.base);
+        if (s.kernel_done) (void)hipEventDestroy(s.kernel_done);
+    }
+    if (e->copy_done) (void)hipEventDestroy(e->copy_done);
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    if (e->compute_stream) (void)hipStreamDestroy(e->compute_stream);
+    for (auto& b : e->pool)
+        if (b.data) (void)hipHostFree(b.data);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rpf_abi_version(void) { return RPF_ABI_VERSION; }
+
+int rpf_supported_n(int N) { return rpf::kernel_supported(N) ? 1 : 0; }
+
+const char* rpf_last_global_error(void) { return g_last_error.c_str(); }
+
+int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
+{
+    if (!out) return fail(nullptr, RPF_ERR_INVALID_ARGUMENT, "rpf_engine_create: out is NULL");
+    *out = nullptr;
+    if (!cfg || cfg->struct_size != sizeof(rpf_config))
+        return fail(nullptr, RPF_ERR_INVALID_ARGUMENT, "rpf_engine_create: bad rpf_config size");
+    if (cfg->N < 2 || (cfg->N % 2) != 0)
+        return fail(nullptr, RPF_ERR_INVALID_ARGUMENT,
+                    "Number of bins must be a positive even number.");
+    if (!rpf::kernel_supported(cfg->N))
+        return fail(nullptr, RPF_ERR_INVALID_ARGUMENT,
+                    "No gfx950 kernel for " + std::to_string(cfg->N) +
+                        " bins in this build (supported: powers of two 64..8192).");
+    if (cfg->n_buffers < 1)
+        return fail(nullptr, RPF_ERR_INVALID_ARGUMENT, "Argument to 'buffers' must be a positive number.");
+    if (cfg->buffer_capacity < 2 || (cfg->buffer_capacity % 2) != 0)
+        return fail(nullptr, RPF_ERR_INVALID_ARGUMENT, "Buffer size must be a positive even number of bytes.");
+
+    int ndev = 0;
+    hipError_t err = hipGetDeviceCount(&ndev);
+    if (err != hipSuccess || ndev < 1)
+        return fail(nullptr, RPF_ERR_HARDWARE,
+                    std::string("No HIP device available (") +
+                        (err != hipSuccess ? hipGetErrorString(err) : "device count 0") +
+                        "); this engine has no CPU path.");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, RPF_ERR_INVALID_ARGUMENT, "Invalid HIP device ordinal.");
+
+    rpf_engine* e = new rpf_engine();
+    e->N = cfg->N;
+    e->has_window = cfg->window != nullptr;
+    e->n_buffers = cfg->n_buffers;
+    e->buffer_capacity = static_cast<size_t>(cfg->buffer_capacity);
+    e->device = cfg->device;
+    e->flags = cfg->flags;
+    e->use_dma = !(cfg->flags & RPF_FLAG_NO_LDS_DMA);
+    e->queue_histogram.assign(e->n_buffers + 1, 0);
+    e->pwr.assign(e->N, 0.0);
+
+    auto cleanup = [&](int rc) {
+        release_device(e);
+        delete e;
+        return rc;
+    };
+#define CREATE_TRY(call)                                                                 \
+    do {                                                                                 \
+        hipError_t err__ = (call);                                                       \
+        if (err__ != hipSuccess)                                                         \
+            return cleanup(fail(nullptr, RPF_ERR_HARDWARE,                               \
+                                std::string(#call) + ": " + hipGetErrorString(err__)));  \
+    } while (0)
+
+    CREATE_TRY(hipSetDevice(e->device));
+    CREATE_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&e->compute_stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&e->copy_done, hipEventDisableTiming));
+
+    // "plan": twiddle table on the device (where fftwf_plan_dft_1d stands, datastore.cxx:32)
+    std::vector<rpf::cf> tw;
+    rpf::make_twiddles(e->N, tw);
+    CREATE_TRY(hipMalloc(&e->d_twiddles, sizeof(rpf::cf) * e->N));
+    CREATE_TRY(hipMemcpy(e->d_twiddles, tw.data(), sizeof(rpf::cf) * e->N, hipMemcpyHostToDevice));
+    if (e->has_window) {
+        CREATE_TRY(hipMalloc(&e->d_window, sizeof(float) * e->N));
+        CREATE_TRY(hipMemcpy(e->d_window, cfg->window, sizeof(float) * e->N, hipMemcpyHostToDevice));
+    }
+    CREATE_TRY(rpf::plan_launch(e->N, e->has_window, true, e->device, &e->plan));
+    {
+        rpf::LaunchInfo tmp;
+        CREATE_TRY(rpf::plan_launch(e->N, e->has_window, false, e->device, &tmp));
+        e->plan.grid = std::min(e->plan.grid, tmp.grid);
+    }
+    CREATE_TRY(hipMalloc(&e->d_partial,
+                         sizeof(double) * e->N * static_cast<size_t>(e->plan.grid) * e->plan.fpw));
+    CREATE_TRY(hipMalloc(&e->d_pwr, sizeof(double) * e->N));
+    CREATE_TRY(hipMemset(e->d_pwr, 0, sizeof(double) * e->N));
+
+    // buffer pool: pinned host memory (datastore.cxx:27-28)
+    e->pool.resize(e->n_buffers);
+    for (auto& b : e->pool) {
+        void* p = nullptr;
+        CREATE_TRY(hipHostMalloc(&p, e->buffer_capacity, hipHostMallocDefault));
+        b.data = static_cast<uint8_t*>(p);
+        b.size = e->buffer_capacity;
+        e->empty_buffers.push_back(&b);
+    }
+    // device staging ring: head room for a carried partial frame + one buffer
+    e->head_room = ((2 * static_cast<size_t>(e->N)) + 255) / 256 * 256;
+    e->staging.resize(3);
+    for (auto& s : e->staging) {
+        void* p = nullptr;
+        CREATE_TRY(hipMalloc(&p, e->head_room + e->buffer_capacity));
+        s.base = static_cast<uint8_t*>(p);
+        CREATE_TRY(hipEventCreateWithFlags(&s.kernel_done, hipEventDisableTiming));
+    }
+#undef CREATE_TRY
+    *out = e;
+    return RPF_OK;
+}
+
+void rpf_engine_destroy(rpf_engine* e)
+{
+    if (!e) return;
+    if (e->worker_running) {
+        int64_t dummy;
+        (void)rpf_finish(e, &dummy);
+    }
+    (void)hipSetDevice(e->device);
+    release_device(e);
+    delete e;
+}
+
+const char* rpf_last_error(const rpf_engine* e) { return e ? e->last_error.c_str() : g_last_error.c_str(); }
+
+int rpf_begin(rpf_engine* e, int64_t repeats)
+{
+    if (!e) return fail(nullptr, RPF_ERR_INVALID_ARGUMENT, "rpf_begin: NULL engine");
+    if (e->worker_running) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_begin: acquisition already running");
+    if (repeats < 0) return fail(e, RPF_ERR_INVALID_ARGUMENT, "Argument to 'repeats' must be a positive number.");
+    HIP_TRY(e, hipSetDevice(e->device));
+    // acquisition.cxx:252-254
+    std::fill(e->pwr.begin(), e->pwr.end(), 0.0);
+    HIP_TRY(e, hipMemsetAsync(e->d_pwr, 0, sizeof(double) * e->N, e->compute_stream));
+    {
+        std::lock_guard<std::mutex> lock(e->status_mutex);
+        e->acquisition_finished = false;
+    }
+    e->repeats_done = 0;
+    e->repeats = repeats;
+    e->worker_rc = RPF_OK;
+    e->worker_error.clear();
+    // acquisition.cxx:256
+    e->worker = std::thread(worker_main, e);
+    e->worker_running = true;
+    return RPF_OK;
+}
+
+int rpf_buffer_acquire(rpf_engine* e, uint8_t** buf, size_t* capacity)
+{
+    if (!e || !buf) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_buffer_acquire: NULL argument");
+    // acquisition.cxx:278-285
+    std::unique_lock<std::mutex> lock(e->status_mutex);
+    e->queue_histogram[e->empty_buffers.size()]++;
+    while (e->empty_buffers.empty()) e->status_change.wait(lock);
+    HostBuffer* b = e->empty_buffers.front();
+    e->empty_buffers.pop_front();
+    lock.unlock();
+    *buf = b->data;
+    if (capacity) *capacity = e->buffer_capacity;
+    return RPF_OK;
+}
+
+static HostBuffer* find_buffer(rpf_engine* e, const uint8_t* p)
+{
+    for (auto& b : e->pool)
+        if (b.data == p) return &b;
+    return nullptr;
+}
+
+int rpf_buffer_submit(rpf_engine* e, uint8_t* buf, size_t nbytes)
+{
+    if (!e) return fail(nullptr, RPF_ERR_INVALID_ARGUMENT, "rpf_buffer_submit: NULL engine");
+    HostBuffer* b = find_buffer(e, buf);
+    if (!b) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_buffer_submit: not an engine buffer");
+    if (nbytes > e->buffer_capacity || (nbytes % 2) != 0)
+        return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_buffer_submit: size must be even and <= capacity");
+    if (!e->worker_running) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_buffer_submit: no acquisition running");
+    b->size = nbytes;   // buffer.resize(dataNeeded), acquisition.cxx:302
+    // acquisition.cxx:320-323
+    std::lock_guard<std::mutex> lock(e->status_mutex);
+    e->occupied_buffers.push_back(b);
+    e->status_change.notify_all();
+    return RPF_OK;
+}
+
+int rpf_buffer_unget(rpf_engine* e, uint8_t* buf)
+{
+    if (!e) return fail(nullptr, RPF_ERR_INVALID_ARGUMENT, "rpf_buffer_unget: NULL engine");
+    HostBuffer* b = find_buffer(e, buf);
+    if (!b) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_buffer_unget: not an engine buffer");
+    // acquisition.cxx:310-314 (no notify needed)
+    std::lock_guard<std::mutex> lock(e->status_mutex);
+    e->empty_buffers.push_front(b);
+    return RPF_OK;
+}
+
+int rpf_finish(rpf_engine* e, int64_t* repeats_done)
+{
+    if (!e) return fail(nullptr, RPF_ERR_INVALID_ARGUMENT, "rpf_finish: NULL engine");
+    if (!e->worker_running) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_finish: no acquisition running");
+    // acquisition.cxx:343-347
+    {
+        std::lock_guard<std::mutex> lock(e->status_mutex);
+        e->acquisition_finished = true;
+        e->status_change.notify_all();
+    }
+    e->worker.join();
+    e->worker_running = false;
+    if (repeats_done) *repeats_done = e->repeats_done;
+    if (e->worker_rc != RPF_OK) return fail(e, e->worker_rc, e->worker_error);
+    return RPF_OK;
+}
+
+int rpf_get_power(const rpf_engine* e, double* out)
+{
+    if (!e || !out) return RPF_ERR_INVALID_ARGUMENT;
+    std::memcpy(out, e->pwr.data(), sizeof(double) * e->N);
+    return RPF_OK;
+}
+
+int64_t rpf_get_repeats_done(const rpf_engine* e) { return e ? e->repeats_done : 0; }
+
+int rpf_get_histogram(const rpf_engine* e, int* out)
+{
+    if (!e || !out) return RPF_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(const_cast<rpf_engine*>(e)->status_mutex);
+    std::memcpy(out, e->queue_histogram.data(), sizeof(int) * e->queue_histogram.size());
+    return RPF_OK;
+}
+
+int rpf_accumulate(rpf_engine* e, const uint8_t* stream, size_t nbytes, int64_t repeats,
+                   double* pwr_out, int64_t* repeats_done)
+{
+    if (!e || (!stream && nbytes)) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_accumulate: NULL argument");
+    int rc = rpf_begin(e, repeats);
+    if (rc != RPF_OK) return rc;
+    size_t pos = 0;
+    const size_t cap = e->buffer_capacity;
+    while (pos < nbytes) {
+        uint8_t* buf = nullptr;
+        rc = rpf_buffer_acquire(e, &buf, nullptr);
+        if (rc != RPF_OK) break;
+        const size_t n = std::min(cap, (nbytes - pos) & ~static_cast<size_t>(1));
+        if (n == 0) {
+            rpf_buffer_unget(e, buf);
+            break;
+        }
+        std::memcpy(buf, stream + pos, n);
+        rc = rpf_buffer_submit(e, buf, n);
+        if (rc != RPF_OK) break;
+        pos += n;
+    }
+    int64_t done = 0;
+    int rc2 = rpf_finish(e, &done);
+    if (rc == RPF_OK) rc = rc2;
+    if (repeats_done) *repeats_done = done;
+    if (rc == RPF_OK && pwr_out) std::memcpy(pwr_out, e->pwr.data(), sizeof(double) * e->N);
+    return rc;
+}
+
+int rpf_accumulate_device(rpf_engine* e, const void* d_stream, size_t nbytes, int64_t repeats,
+                          double* d_pwr_out, void* hip_stream, int64_t* repeats_done)
+{
+    if (!e || !d_pwr_out || (!d_stream && nbytes))
+        return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_accumulate_device: NULL argument");
+    if (e->worker_running)
+        return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_accumulate_device: acquisition running");
+    if (repeats < 0) return fail(e, RPF_ERR_INVALID_ARGUMENT, "Argument to 'repeats' must be a positive number.");
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->compute_stream;
+    int64_t nframes = static_cast<int64_t>(nbytes / (2 * static_cast<size_t>(e->N)));
+    nframes = std::min(nframes, repeats);
+    if (repeats_done) *repeats_done = nframes;
+    if (nframes == 0) {
+        HIP_TRY(e, hipMemsetAsync(d_pwr_out, 0, sizeof(double) * e->N, s));
+        return RPF_OK;
+    }
+    return launch_frames(e, static_cast<const uint8_t*>(d_stream), nframes, d_pwr_out,
+                         /*accumulate=*/false, s);
+}
+
+int rpf_last_launch_info(const rpf_engine* e, int* grid, int* block, int* frames_per_wg,
+                         int* lds_bytes)
+{
+    if (!e) return RPF_ERR_INVALID_ARGUMENT;
+    if (grid) *grid = e->last.grid ? e->last.grid : e->plan.grid;
+    if (block) *block = e->plan.block;
+    if (frames_per_wg) *frames_per_wg = e->plan.fpw;
+    if (lds_bytes) *lds_bytes = e->plan.lds_bytes;
+    return RPF_OK;
+}
+
+}  // extern "C"

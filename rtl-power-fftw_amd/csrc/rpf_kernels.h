@@ -1,0 +1,45 @@
+// rpf_kernels.h -- internal C++ interface between the engine (rpf_engine.cpp)
+// and the gfx950 kernels (rpf_kernels.hip).  Not part of the C-ABI.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "fft_core.h"
+
+namespace rpf {
+
+struct LaunchInfo {
+    int grid = 0;        // workgroups
+    int block = 0;       // threads per workgroup
+    int fpw = 0;         // frames processed concurrently by one workgroup
+    int lds_bytes = 0;   // dynamic LDS per workgroup
+};
+
+// Is there a fused kernel for N bins?
+bool kernel_supported(int N);
+
+// Persistent-grid geometry for N on `device`: li->grid is the number of
+// workgroups that are simultaneously resident (occupancy x CU count).
+hipError_t plan_launch(int N, bool window, bool use_dma, int device, LaunchInfo* li);
+
+// Fused unpack + FFT + |X|^2 accumulate over frames [0, nframes) of d_stream
+// (frame f = bytes [2N f, 2N (f+1))).  Writes li.grid*li.fpw partial spectra of
+// N doubles each to d_partial (every slot is written, zeros included).
+// `grid` is the number of workgroups to launch (<= the planned grid).
+hipError_t launch_fft_accum(int N, bool window, bool use_dma, const uint8_t* d_stream,
+                            long nframes, const cf* d_twiddles, const float* d_window,
+                            double* d_partial, int grid, hipStream_t stream, LaunchInfo* li);
+
+// d_out[bin] = (accumulate ? d_out[bin] : 0) + sum_{s < nslots} d_partial[s*N + bin],
+// summed in slot order (deterministic).
+hipError_t launch_reduce(const double* d_partial, int nslots, int N, double* d_out,
+                         bool accumulate, hipStream_t stream);
+
+// Master twiddle table W_N^k = exp(-2 pi i k / N), k in [0,N), evaluated in
+// long double and rounded once to float.
+void make_twiddles(int N, std::vector<cf>& out);
+
+}  // namespace rpf

@@ -1,0 +1,309 @@
+// rpf_kernels.hip -- gfx950 (CDNA4) kernels of the power-spectrum engine.
+//
+// K1  fft_accum_kernel   fused  u8-IQ unpack -> (-1)^n -> window -> FFT -> |X|^2 (f64)
+//                        replaces the body of Datastore::fftThread
+//                        (/root/reference/src/datastore.cxx:66-89).
+// K3  reduce_kernel      deterministic sum of the per-workgroup partial spectra
+//                        into pwr[N] (Datastore::pwr, datastore.h:53).
+//
+// K1 layout.  One frame (N complex samples = 2N bytes of HBM) is owned by
+// T = N/P threads holding P points each; a 256-thread (or T-thread, if larger)
+// workgroup runs WG/T frames side by side and walks the stream persistently
+// (frame f -> workgroup (f / FPW) mod grid).  Per frame:
+//   1. the 2N raw bytes arrive in LDS by LDS-DMA (global_load_lds_dwordx4,
+//      16 B per lane, fully coalesced, no VGPR round trip), issued one frame
+//      ahead so the HBM latency hides under the previous frame's butterflies;
+//   2. each thread picks its P samples (stride T) out of LDS with ds_read_u16,
+//      converts (v_cvt_f32_ubyteN), removes the 127 offset, applies (-1)^n and
+//      the window -- all exact except the single window rounding;
+//   3. radix-P butterflies in registers, twiddles held in registers for the
+//      whole kernel, one padded LDS exchange between passes (bank-conflict
+//      free, fft_core.h); exchanges that stay inside a wavefront need no
+//      s_barrier;
+//   4. |X|^2 is added in double into P per-thread register accumulators that
+//      live for the whole kernel; they are written once, at the end, as one
+//      partial spectrum per frame slot.
+// HBM traffic per frame is therefore exactly the 2N input bytes; the kernel is
+// bound by VALU + LDS, not by HBM (DESIGN.md has the numbers).  No MFMA.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <type_traits>
+
+#include "rpf_kernels.h"
+
+namespace rpf {
+
+namespace {
+
+// Orders LDS traffic between the threads that exchange data: a workgroup
+// barrier when a frame spans several wavefronts, otherwise only a compiler
+// fence (one wavefront's DS instructions execute in order).
+template <bool BLOCK>
+__device__ __forceinline__ void exchange_sync()
+{
+    if constexpr (BLOCK) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+using gptr_t = const __attribute__((address_space(1))) void*;
+using lptr_t = __attribute__((address_space(3))) void*;
+
+// Stage the raw bytes of the frames this workgroup handles in iteration `fb`
+// (fb = frame index of slot 0).  Wave w, piece i moves the 1 KiB
+// [ (w*PIECES+i)*1024, +1024 ) of the workgroup's raw area, lane l the 16 bytes
+// at +16 l -- i.e. a wave only ever stages bytes of its own frame slot(s).
+template <class G, bool DMA>
+__device__ __forceinline__ void stage_raw(const uint8_t* __restrict__ stream, long fb,
+                                          long nframes, uint8_t* raw_base, int tid)
+{
+    constexpr int PIECES = G::P / 8;
+    constexpr int FRAME_BYTES = 2 * G::N;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int wave_off = (wave * PIECES + i) * 1024;
+        const int B = wave_off + lane * 16;
+        const int slot = B / FRAME_BYTES, off = B % FRAME_BYTES;
+        const long f = fb + slot;
+        if (f < nframes) {
+            const uint8_t* src = stream + f * FRAME_BYTES + off;
+            if constexpr (DMA) {
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(raw_base + wave_off), 16, 0,
+                                                 0);
+            } else {
+                *reinterpret_cast<uint4*>(raw_base + B) = *reinterpret_cast<const uint4*>(src);
+            }
+        }
+    }
+}
+
+template <class G, int J>
+__device__ __forceinline__ void load_twiddles(int t, const cf* __restrict__ twN,
+                                              cf (&tw)[G::NPASS - 1][G::P - 1])
+{
+    if constexpr (J < G::NPASS) {
+#pragma unroll
+        for (int r = 1; r < G::P; ++r) tw[J - 1][r - 1] = twN[twiddle_index<G, J>(t, r)];
+        load_twiddles<G, J + 1>(t, twN, tw);
+    }
+}
+
+// Passes J .. NPASS-1: [fetch] -> radix-P butterfly -> twiddle -> store -> sync.
+// Pass J > 1 reads and writes the same LDS slots per thread; the pass-1 store
+// is separated from the previous frame's last reads by the sync at the top of
+// the frame loop.  The exchange after pass J stays inside groups of L_J
+// threads, so it needs a workgroup barrier only if L_J > 64.
+template <class G, bool DMA, int J>
+__device__ __forceinline__ void middle_passes(int t, cf* x,
+                                              const cf (&tw)[G::NPASS - 1][G::P - 1], cf* slab,
+                                              const uint8_t* __restrict__ stream, long fb_next,
+                                              long nframes, uint8_t* raw_base, int tid)
+{
+    if constexpr (J < G::NPASS) {
+        if constexpr (J > 1) phase_fetch<G, J>(t, x, slab);
+        phase_butterfly_twiddle<G>(x, tw[J - 1]);
+        phase_store<G, J>(t, x, slab);
+        exchange_sync<(G::Lcur(J) > 64)>();
+        if constexpr (J == 1) {
+            // every raw read of this frame is done: stage the next frame
+            if (fb_next < nframes) stage_raw<G, DMA>(stream, fb_next, nframes, raw_base, tid);
+        }
+        middle_passes<G, DMA, J + 1>(t, x, tw, slab, stream, fb_next, nframes, raw_base, tid);
+    }
+}
+
+template <class G, int WG, int OCC, bool WINDOW, bool DMA>
+__global__ __launch_bounds__(WG, (OCC * WG) / 256) void fft_accum_kernel(const uint8_t* __restrict__ stream,
+                                                       long nframes,
+                                                       const cf* __restrict__ twN,
+                                                       const float* __restrict__ window,
+                                                       double* __restrict__ partial)
+{
+    constexpr int P = G::P, T = G::T, N = G::N, NPASS = G::NPASS;
+    constexpr int FPW = WG / T;
+    constexpr bool BLOCK_SYNC = (T > 64);
+    static_assert(WG % T == 0 && WG % 64 == 0, "");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* const slab_base = reinterpret_cast<cf*>(smem);                      // [FPW][LDS_CPX]
+    uint8_t* const raw_base = smem + FPW * G::LDS_CPX * sizeof(cf);        // [FPW][2N]
+
+    const int tid = threadIdx.x;
+    const int fs = tid / T, t = tid % T;
+    cf* const slab = slab_base + fs * G::LDS_CPX;
+    const uint8_t* const raw = raw_base + fs * 2 * N;
+
+    // Loop-invariant per-thread constants: twiddles, sign, window.
+    cf tw[NPASS - 1][P - 1];
+    load_twiddles<G, 1>(t, twN, tw);
+    const float sgn = (t & 1) ? -1.0f : 1.0f;
+    float wsgn[P];
+    if constexpr (WINDOW) {
+#pragma unroll
+        for (int a = 0; a < P; ++a) wsgn[a] = window[t + T * a] * sgn;
+    }
+    double acc[P];
+#pragma unroll
+    for (int a = 0; a < P; ++a) acc[a] = 0.0;
+
+    const long stride = static_cast<long>(gridDim.x) * FPW;
+    long fb = static_cast<long>(blockIdx.x) * FPW;
+    if (fb < nframes) stage_raw<G, DMA>(stream, fb, nframes, raw_base, tid);
+
+    for (; fb < nframes; fb += stride) {
+        const bool active = (fb + fs) < nframes;
+        cf x[P];
+
+        // raw bytes of this frame have landed
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        exchange_sync<BLOCK_SYNC>();
+        phase_unpack<G, WINDOW>(t, raw, sgn, wsgn, x);
+
+        // passes 1 .. NPASS-1: butterfly, twiddle, exchange (+ prefetch of the
+        // next frame's raw bytes once this frame's have all been read)
+        middle_passes<G, DMA, 1>(t, x, tw, slab, stream, fb + stride, nframes, raw_base, tid);
+        phase_fetch<G, NPASS>(t, x, slab);
+        phase_last<G>(x);
+        if (active) phase_accumulate(x, acc, P);
+        // The next iteration's first LDS write (pass-1 store) is separated from
+        // this iteration's last reads by the sync at the top of the loop.
+    }
+
+    // One partial spectrum per frame slot; every slot is written (zeros too).
+    double* out = partial + (static_cast<size_t>(blockIdx.x) * FPW + fs) * N;
+#pragma unroll
+    for (int a = 0; a < P; ++a) out[bin_of<G>(t, a)] = acc[a];
+}
+
+constexpr int RED_BINS = 16, RED_GROUPS = 16;
+
+__global__ __launch_bounds__(RED_BINS* RED_GROUPS) void reduce_kernel(
+    const double* __restrict__ partial, int nslots, int N, double* __restrict__ out,
+    int accumulate)
+{
+    __shared__ double red[RED_GROUPS][RED_BINS + 1];
+    const int b = threadIdx.x % RED_BINS, g = threadIdx.x / RED_BINS;
+    const int bin = blockIdx.x * RED_BINS + b;
+    double s = 0.0;
+    if (bin < N)
+        for (int sl = g; sl < nslots; sl += RED_GROUPS) s += partial[static_cast<size_t>(sl) * N + bin];
+    red[g][b] = s;
+    __syncthreads();
+    if (g == 0 && bin < N) {
+        double tot = accumulate ? out[bin] : 0.0;
+#pragma unroll
+        for (int k = 0; k < RED_GROUPS; ++k) tot += red[k][b];
+        out[bin] = tot;
+    }
+}
+
+// ---------------------------------------------------------------- dispatch --
+using KernelFn = void (*)(const uint8_t*, long, const cf*, const float*, double*);
+
+struct Variant {
+    int N, P, WG, fpw, lds_bytes;
+    KernelFn fn[2][2];   // [window][dma]
+};
+
+// OCC = workgroup-equivalents of 256 threads the register budget must admit per
+// CU (waves per SIMD).
+template <int N, int P, int OCC>
+Variant make_variant()
+{
+    using G = Geom<N, P>;
+    constexpr int WG = G::T >= 256 ? G::T : 256;
+    constexpr int FPW = WG / G::T;
+    constexpr int LDS = FPW * (G::LDS_CPX * (int)sizeof(cf) + 2 * N);
+    return Variant{N, P, WG, FPW, LDS,
+                   {{fft_accum_kernel<G, WG, OCC, false, false>,
+                     fft_accum_kernel<G, WG, OCC, false, true>},
+                    {fft_accum_kernel<G, WG, OCC, true, false>,
+                     fft_accum_kernel<G, WG, OCC, true, true>}}};
+}
+
+const Variant kVariants[] = {
+    make_variant<64, 8, 4>(),    make_variant<128, 8, 4>(),   make_variant<256, 8, 4>(),
+    make_variant<512, 8, 4>(),   make_variant<1024, 16, 2>(), make_variant<2048, 16, 2>(),
+    make_variant<4096, 16, 2>(), make_variant<8192, 16, 1>(),
+};
+
+const Variant* find_variant(int N)
+{
+    for (const Variant& v : kVariants)
+        if (v.N == N) return &v;
+    return nullptr;
+}
+
+}  // namespace
+
+bool kernel_supported(int N) { return find_variant(N) != nullptr; }
+
+hipError_t plan_launch(int N, bool window, bool use_dma, int device, LaunchInfo* li)
+{
+    const Variant* v = find_variant(N);
+    if (!v) return hipErrorInvalidValue;
+    KernelFn fn = v->fn[window ? 1 : 0][use_dma ? 1 : 0];
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, v->lds_bytes);
+    if (err != hipSuccess) return err;
+    int per_cu = 0;
+    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn),
+                                                       v->WG, v->lds_bytes);
+    if (err != hipSuccess) return err;
+    hipDeviceProp_t prop;
+    err = hipGetDeviceProperties(&prop, device);
+    if (err != hipSuccess) return err;
+    if (per_cu < 1) per_cu = 1;
+    li->grid = per_cu * prop.multiProcessorCount;
+    li->block = v->WG;
+    li->fpw = v->fpw;
+    li->lds_bytes = v->lds_bytes;
+    return hipSuccess;
+}
+
+hipError_t launch_fft_accum(int N, bool window, bool use_dma, const uint8_t* d_stream,
+                            long nframes, const cf* d_twiddles, const float* d_window,
+                            double* d_partial, int grid, hipStream_t stream, LaunchInfo* li)
+{
+    const Variant* v = find_variant(N);
+    if (!v || grid < 1) return hipErrorInvalidValue;
+    KernelFn fn = v->fn[window ? 1 : 0][use_dma ? 1 : 0];
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(v->WG), v->lds_bytes, stream, d_stream, nframes,
+                       d_twiddles, d_window, d_partial);
+    if (li) {
+        li->grid = grid;
+        li->block = v->WG;
+        li->fpw = v->fpw;
+        li->lds_bytes = v->lds_bytes;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce(const double* d_partial, int nslots, int N, double* d_out,
+                         bool accumulate, hipStream_t stream)
+{
+    const int blocks = (N + RED_BINS - 1) / RED_BINS;
+    hipLaunchKernelGGL(reduce_kernel, dim3(blocks), dim3(RED_BINS * RED_GROUPS), 0, stream,
+                       d_partial, nslots, N, d_out, accumulate ? 1 : 0);
+    return hipGetLastError();
+}
+
+void make_twiddles(int N, std::vector<cf>& out)
+{
+    out.resize(N);
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (int k = 0; k < N; ++k) {
+        const long double a = two_pi * static_cast<long double>(k) / static_cast<long double>(N);
+        out[k].x = static_cast<float>(cosl(a));
+        out[k].y = static_cast<float>(-sinl(a));
+    }
+}
+
+}  // namespace rpf
