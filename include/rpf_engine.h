@@ -56,6 +56,9 @@ typedef struct rpf_config {
 #define RPF_FLAG_NONE 0u
 /* Stage raw bytes through VGPRs instead of LDS-DMA (debug / A-B measurement). */
 #define RPF_FLAG_NO_LDS_DMA 1u
+/* Tuning: select kernel variant k (0 = default) for this N; an unknown variant
+ * makes rpf_engine_create fail with RPF_ERR_INVALID_ARGUMENT. */
+#define RPF_FLAG_VARIANT(k) (((uint32_t)(k) & 0xffu) << 8)
 
 /* ABI version of the loaded library. */
 int rpf_abi_version(void);
@@ -111,12 +114,21 @@ int rpf_accumulate(rpf_engine* e, const uint8_t* stream, size_t nbytes, int64_t 
 
 /* Device-resident replay: the stream already sits in HBM (d_stream, 16-byte
  * aligned).  Enqueues the fused kernel and the partial-sum reduce on
- * `hip_stream` (a hipStream_t, NULL = the engine's own stream) and returns
+ * `hip_stream` (a hipStream_t; NULL = HIP's null stream) and returns
  * without synchronising; d_pwr_out[N] (device doubles) is overwritten with the
  * sum over frames [0, min(repeats, nbytes/(2N))).  Used by bench.py and the
  * full-size parity tests; does not touch the buffer queues. */
 int rpf_accumulate_device(rpf_engine* e, const void* d_stream, size_t nbytes, int64_t repeats,
                           double* d_pwr_out, void* hip_stream, int64_t* repeats_done);
+
+/* The two halves of rpf_accumulate_device as separate enqueues, so that a
+ * benchmark can bracket the dominant kernel alone with events on `hip_stream`:
+ * _fused runs K1 (unpack+FFT+|X|^2) and leaves one partial spectrum per frame
+ * slot in engine scratch; _reduce runs K3 over the scratch of the last _fused
+ * call into d_pwr_out[N]. */
+int rpf_device_fused(rpf_engine* e, const void* d_stream, size_t nbytes, int64_t repeats,
+                     void* hip_stream, int64_t* repeats_done);
+int rpf_device_reduce(rpf_engine* e, double* d_pwr_out, void* hip_stream);
 
 /* Launch geometry of the last fused-kernel launch (for DESIGN/bench reporting):
  * workgroups, threads per workgroup, frames per workgroup, LDS bytes. */

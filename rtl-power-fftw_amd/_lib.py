@@ -66,6 +66,9 @@ _SYMBOLS = [
                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     ("rpf_accumulate_device", ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.c_int64, _P, _P,
                                              ctypes.POINTER(ctypes.c_int64)]),
+    ("rpf_device_fused", ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.c_int64, _P,
+                                        ctypes.POINTER(ctypes.c_int64)]),
+    ("rpf_device_reduce", ctypes.c_int, [_P, _P, _P]),
     ("rpf_last_launch_info", ctypes.c_int, [_P] + [ctypes.POINTER(ctypes.c_int)] * 4),
 ]
 
@@ -75,7 +78,8 @@ def symbol_names():
 
 
 def lib_path():
-    return os.path.join(_HERE, "librpf_engine.so")
+    # RPF_ENGINE_LIB: alternative build of the same library (A/B measurements)
+    return os.environ.get("RPF_ENGINE_LIB") or os.path.join(_HERE, "librpf_engine.so")
 
 
 def build(force=False):

@@ -32,15 +32,59 @@
 
 namespace rpf {
 
-struct cf {
-    float x, y;
-};
+// A complex float is one 64-bit register pair (re, im): complex add/sub and the
+// real-scalar products are single packed-f32 instructions (v_pk_add_f32,
+// v_pk_mul_f32, v_pk_fma_f32), and the lane swaps / sign flips that complex
+// arithmetic needs (multiply by -i, the cross terms of a complex product) ride
+// on the VOP3P op_sel / neg modifiers of those instructions instead of costing
+// moves.  hipcc does not form those modifier patterns from C++ (it emits
+// v_mov/v_xor pairs), so the three primitives below are one-instruction inline
+// asm on the device and plain C++ in the host emulator.
+typedef float cf __attribute__((ext_vector_type(2)));
 
-RPF_HD cf operator+(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
-RPF_HD cf operator-(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
-RPF_HD cf cmul(cf a, cf w) { return {a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
-// multiply by -i
-RPF_HD cf mul_mi(cf a) { return {a.y, -a.x}; }
+// d.lo = (+-)a[S0L] + (+-)b[S1L],  d.hi = (+-)a[S0H] + (+-)b[S1H]
+// (S* selects the .x (0) or .y (1) half of the source, N* negates it).
+template <int S0L, int S0H, int N0L, int N0H, int S1L, int S1H, int N1L, int N1H>
+RPF_HD cf pk_add_mod(cf a, cf b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    cf d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[%3,%4] op_sel_hi:[%5,%6] neg_lo:[%7,%8] neg_hi:[%9,%10]"
+        : "=v"(d)
+        : "v"(a), "v"(b), "i"(S0L), "i"(S1L), "i"(S0H), "i"(S1H), "i"(N0L), "i"(N1L), "i"(N0H),
+          "i"(N1H));
+    return d;
+#else
+    const float al = S0L ? a.y : a.x, ah = S0H ? a.y : a.x;
+    const float bl = S1L ? b.y : b.x, bh = S1H ? b.y : b.x;
+    return cf{(N0L ? -al : al) + (N1L ? -bl : bl), (N0H ? -ah : ah) + (N1H ? -bh : bh)};
+#endif
+}
+
+// a + (-i) b = (a.x + b.y, a.y - b.x)
+RPF_HD cf add_mi(cf a, cf b) { return pk_add_mod<0, 1, 0, 0, 1, 0, 0, 1>(a, b); }
+// a - (-i) b = (a.x - b.y, a.y + b.x)
+RPF_HD cf sub_mi(cf a, cf b) { return pk_add_mod<0, 1, 0, 0, 1, 0, 1, 0>(a, b); }
+// -i a = (a.y, -a.x)   and   i a = (-a.y, a.x)
+RPF_HD cf mul_mi(cf a) { return pk_add_mod<1, 0, 0, 1, 0, 0, 0, 0>(a, cf{0.0f, 0.0f}); }
+RPF_HD cf mul_pi(cf a) { return pk_add_mod<1, 0, 1, 0, 0, 0, 0, 0>(a, cf{0.0f, 0.0f}); }
+
+// complex product a*w = (a.x w.x - a.y w.y, a.x w.y + a.y w.x): two instructions
+RPF_HD cf cmul(cf a, cf w)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    cf t, d;
+    // t = (a.x w.x, a.y w.x)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    // d = (a.y (-w.y) + t.x, a.x w.y + t.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+        : "=v"(d)
+        : "v"(a), "v"(w), "v"(t));
+    return d;
+#else
+    return cf{__builtin_fmaf(-a.y, w.y, a.x * w.x), __builtin_fmaf(a.x, w.y, a.y * w.x)};
+#endif
+}
 
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
@@ -114,19 +158,20 @@ RPF_HD cf mul_w16(cf a)
     constexpr int k = ((K16 % 16) + 16) % 16;
     if constexpr (k == 0) return a;
     else if constexpr (k == 4) return mul_mi(a);
-    else if constexpr (k == 8) return {-a.x, -a.y};
-    else if constexpr (k == 12) return {-a.y, a.x};
-    else if constexpr (k == 2) return {(a.x + a.y) * kH, (a.y - a.x) * kH};
-    else if constexpr (k == 6) return {(a.y - a.x) * kH, -(a.x + a.y) * kH};
-    else if constexpr (k == 10) return {-(a.x + a.y) * kH, (a.x - a.y) * kH};
-    else if constexpr (k == 14) return {(a.x - a.y) * kH, (a.x + a.y) * kH};
+    else if constexpr (k == 8) return -a;
+    else if constexpr (k == 12) return mul_pi(a);
+    // odd multiples of 45 degrees: W = +-H (1 -+ i), one swizzled add and one scale
+    else if constexpr (k == 2) return add_mi(a, a) * kH;
+    else if constexpr (k == 6) return sub_mi(a, a) * -kH;
+    else if constexpr (k == 10) return add_mi(a, a) * -kH;
+    else if constexpr (k == 14) return sub_mi(a, a) * kH;
     else {
-        // odd k: (c, -s) with c,s from {C1,S1} and signs by quadrant
+        // odd k: W = (c, -s) with c,s from {C1,S1} and signs by quadrant
         constexpr float c = (k == 1 || k == 15) ? kC1 : (k == 3 || k == 13) ? kS1
                           : (k == 5 || k == 11) ? -kS1 : -kC1;            // cos(2 pi k/16)
         constexpr float s = (k == 1 || k == 7) ? kS1 : (k == 3 || k == 5) ? kC1
                           : (k == 9 || k == 15) ? -kS1 : -kC1;            // sin(2 pi k/16)
-        return {a.x * c + a.y * s, a.y * c - a.x * s};                    // a * (c - i s)
+        return cmul(a, cf{c, -s});
     }
 }
 
@@ -150,11 +195,11 @@ struct Dft<4> {
     static RPF_HD void run(cf* v)
     {
         const cf apc = v[0] + v[2], amc = v[0] - v[2];
-        const cf bpd = v[1] + v[3], jbmd = mul_mi(v[1] - v[3]);
+        const cf bpd = v[1] + v[3], bmd = v[1] - v[3];
         v[0] = apc + bpd;
-        v[1] = amc + jbmd;
+        v[1] = add_mi(amc, bmd);   // amc - i bmd
         v[2] = apc - bpd;
-        v[3] = amc - jbmd;
+        v[3] = sub_mi(amc, bmd);   // amc + i bmd
     }
 };
 
@@ -213,24 +258,29 @@ struct Dft<16> {
 // Unpack P samples of one frame for pass 1 (datastore.cxx:73-77).  `raw` points
 // at the frame's 2N interleaved bytes.  sgn = (-1)^t (n = t + T a and T is even).
 // wsgn: per-register window values already multiplied by sgn, or nullptr.
+// u8 -> f32 without a (half-rate) v_cvt: OR the byte into the mantissa of 2^23,
+// i.e. bits 0x4B0000bb are the float 8388608 + b exactly.
+RPF_HD float byte_plus_2p23(uint32_t b)
+{
+    return __builtin_bit_cast(float, 0x4B000000u | b);
+}
+constexpr float kTwo23 = 8388608.0f;
+
 template <class G, bool WINDOW>
 RPF_HD void phase_unpack(int t, const uint8_t* raw, float sgn, const float* wsgn, cf* x)
 {
-    const float off = -127.0f * sgn;
+    // (2^23 + v) * sgn - (2^23 + 127) * sgn = (v - 127) * sgn, every step exact
+    const float off = -(kTwo23 + 127.0f) * sgn;
 #pragma unroll
     for (int a = 0; a < G::P; ++a) {
         const int n = t + G::T * a;
-        const uint16_t iq = *reinterpret_cast<const uint16_t*>(raw + 2 * n);
-        const float fi = static_cast<float>(iq & 0xffu);
-        const float fq = static_cast<float>(iq >> 8);
+        const uint32_t iq = *reinterpret_cast<const uint16_t*>(raw + 2 * n);
+        const cf f = cf{byte_plus_2p23(iq & 0xffu), byte_plus_2p23(iq >> 8)};
         if constexpr (WINDOW) {
             // (v - 127) is exact, * (+-w) rounds once: same value as the reference
-            x[a].x = (fi - 127.0f) * wsgn[a];
-            x[a].y = (fq - 127.0f) * wsgn[a];
+            x[a] = (f - (kTwo23 + 127.0f)) * wsgn[a];
         } else {
-            // v*sgn - 127*sgn, exact in float
-            x[a].x = fi * sgn + off;
-            x[a].y = fq * sgn + off;
+            x[a] = f * sgn + off;
         }
     }
 }
@@ -276,22 +326,34 @@ RPF_HD void phase_store(int t, const cf* x, cf* slab)
 #pragma unroll
     for (int a = 0; a < G::P; ++a) p[slot_delta<G, J>(a)] = x[a];
 }
+// On the device the fetch goes through a volatile LDS-address-space pointer only
+// to keep hipcc from pairing the loads into ds_read2_b64, which moves half the
+// bytes per LDS cycle of two ds_read_b64 (MI355X_MICROARCH.md, LDS table).
+// RPF_LDS_PLAIN_FETCH builds the plain-pointer variant for A/B measurement.
 template <class G, int J>
 RPF_HD void phase_fetch(int t, cf* x, const cf* slab)
 {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RPF_LDS_PLAIN_FETCH)
+    using lds_cf = const volatile __attribute__((address_space(3))) cf;
+    lds_cf* const p = (lds_cf*)(slab + slot_base<G, J>(t));
+#else
     const cf* const p = slab + slot_base<G, J>(t);
+#endif
 #pragma unroll
     for (int a = 0; a < G::P; ++a) x[a] = p[slot_delta<G, J>(a)];
 }
 
-// |X|^2 in double, as the reference's pow(float,2)+pow(float,2) (datastore.cxx:84).
+// pwr += Re^2 + Im^2 in double (datastore.cxx:83-85).  The reference rounds
+// Re^2+Im^2 (both squares exact in double) and then the running sum; here each
+// exact square is folded in by its own fused multiply-add -- also two roundings
+// per bin and frame, ~1e-16 relative, but two half-rate instructions fewer.
 RPF_HD void phase_accumulate(const cf* x, double* acc, int P)
 {
 #pragma unroll
     for (int a = 0; a < P; ++a) {
         const double re = static_cast<double>(x[a].x);
         const double im = static_cast<double>(x[a].y);
-        acc[a] += re * re + im * im;
+        acc[a] = __builtin_fma(im, im, __builtin_fma(re, re, acc[a]));
     }
 }
 

@@ -59,6 +59,7 @@ struct rpf_engine {
     int device = 0;
     uint32_t flags = 0;
     bool use_dma = true;
+    int variant = 0;
 
     // Datastore public state
     int64_t repeats = 0;        // params.repeats of the running acquisition
@@ -118,9 +119,9 @@ int launch_frames(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, doubl
     const bool dma = e->use_dma && aligned;
     const int64_t wanted = (nframes + e->plan.fpw - 1) / e->plan.fpw;
     const int grid = static_cast<int>(std::min<int64_t>(e->plan.grid, wanted));
-    HIP_TRY(e, rpf::launch_fft_accum(e->N, e->has_window, dma, d_frames, nframes, e->d_twiddles,
+    HIP_TRY(e, rpf::launch_fft_accum(e->N, e->variant, e->has_window, dma, d_frames, nframes, e->d_twiddles,
                                      e->d_window, e->d_partial, grid, stream, &e->last));
-    HIP_TRY(e, rpf::launch_reduce(e->d_partial, grid * e->plan.fpw, e->N, d_out, accumulate,
+    HIP_TRY(e, rpf::launch_reduce(e->d_partial, grid, e->N, d_out, accumulate,
                                   stream));
     return RPF_OK;
 }
@@ -262,7 +263,8 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
     if (cfg->N < 2 || (cfg->N % 2) != 0)
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT,
                     "Number of bins must be a positive even number.");
-    if (!rpf::kernel_supported(cfg->N))
+    const int variant = static_cast<int>((cfg->flags >> 8) & 0xffu);
+    if (!rpf::kernel_supported(cfg->N, variant))
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT,
                     "No gfx950 kernel for " + std::to_string(cfg->N) +
                         " bins in this build (supported: powers of two 64..8192).");
@@ -289,6 +291,7 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
     e->device = cfg->device;
     e->flags = cfg->flags;
     e->use_dma = !(cfg->flags & RPF_FLAG_NO_LDS_DMA);
+    e->variant = variant;
     e->queue_histogram.assign(e->n_buffers + 1, 0);
     e->pwr.assign(e->N, 0.0);
 
@@ -319,14 +322,14 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         CREATE_TRY(hipMalloc(&e->d_window, sizeof(float) * e->N));
         CREATE_TRY(hipMemcpy(e->d_window, cfg->window, sizeof(float) * e->N, hipMemcpyHostToDevice));
     }
-    CREATE_TRY(rpf::plan_launch(e->N, e->has_window, true, e->device, &e->plan));
+    CREATE_TRY(rpf::plan_launch(e->N, e->variant, e->has_window, true, e->device, &e->plan));
     {
         rpf::LaunchInfo tmp;
-        CREATE_TRY(rpf::plan_launch(e->N, e->has_window, false, e->device, &tmp));
+        CREATE_TRY(rpf::plan_launch(e->N, e->variant, e->has_window, false, e->device, &tmp));
         e->plan.grid = std::min(e->plan.grid, tmp.grid);
     }
     CREATE_TRY(hipMalloc(&e->d_partial,
-                         sizeof(double) * e->N * static_cast<size_t>(e->plan.grid) * e->plan.fpw));
+                         sizeof(double) * e->N * static_cast<size_t>(e->plan.grid)));
     CREATE_TRY(hipMalloc(&e->d_pwr, sizeof(double) * e->N));
     CREATE_TRY(hipMemset(e->d_pwr, 0, sizeof(double) * e->N));
 
@@ -511,7 +514,7 @@ int rpf_accumulate_device(rpf_engine* e, const void* d_stream, size_t nbytes, in
     if (e->worker_running)
         return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_accumulate_device: acquisition running");
     if (repeats < 0) return fail(e, RPF_ERR_INVALID_ARGUMENT, "Argument to 'repeats' must be a positive number.");
-    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->compute_stream;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the HIP null stream
     int64_t nframes = static_cast<int64_t>(nbytes / (2 * static_cast<size_t>(e->N)));
     nframes = std::min(nframes, repeats);
     if (repeats_done) *repeats_done = nframes;
@@ -521,6 +524,34 @@ int rpf_accumulate_device(rpf_engine* e, const void* d_stream, size_t nbytes, in
     }
     return launch_frames(e, static_cast<const uint8_t*>(d_stream), nframes, d_pwr_out,
                          /*accumulate=*/false, s);
+}
+
+int rpf_device_fused(rpf_engine* e, const void* d_stream, size_t nbytes, int64_t repeats,
+                     void* hip_stream, int64_t* repeats_done)
+{
+    if (!e || !d_stream) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_fused: NULL argument");
+    if (e->worker_running) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_fused: acquisition running");
+    int64_t nframes = static_cast<int64_t>(nbytes / (2 * static_cast<size_t>(e->N)));
+    nframes = std::min(nframes, repeats);
+    if (nframes < 1) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_fused: no whole frame");
+    if (repeats_done) *repeats_done = nframes;
+    const uint8_t* d_frames = static_cast<const uint8_t*>(d_stream);
+    const bool dma = e->use_dma && (reinterpret_cast<uintptr_t>(d_frames) % 16) == 0;
+    const int64_t wanted = (nframes + e->plan.fpw - 1) / e->plan.fpw;
+    const int grid = static_cast<int>(std::min<int64_t>(e->plan.grid, wanted));
+    HIP_TRY(e, rpf::launch_fft_accum(e->N, e->variant, e->has_window, dma, d_frames, nframes, e->d_twiddles,
+                                     e->d_window, e->d_partial, grid,
+                                     static_cast<hipStream_t>(hip_stream), &e->last));
+    return RPF_OK;
+}
+
+int rpf_device_reduce(rpf_engine* e, double* d_pwr_out, void* hip_stream)
+{
+    if (!e || !d_pwr_out) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_reduce: NULL argument");
+    if (e->last.grid < 1) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_reduce: nothing to reduce");
+    HIP_TRY(e, rpf::launch_reduce(e->d_partial, e->last.grid, e->N, d_pwr_out,
+                                  /*accumulate=*/false, static_cast<hipStream_t>(hip_stream)));
+    return RPF_OK;
 }
 
 int rpf_last_launch_info(const rpf_engine* e, int* grid, int* block, int* frames_per_wg,

@@ -18,18 +18,18 @@ struct LaunchInfo {
     int lds_bytes = 0;   // dynamic LDS per workgroup
 };
 
-// Is there a fused kernel for N bins?
-bool kernel_supported(int N);
+// Is there a fused kernel for N bins (tuning variant vid, 0 = default)?
+bool kernel_supported(int N, int vid = 0);
 
 // Persistent-grid geometry for N on `device`: li->grid is the number of
 // workgroups that are simultaneously resident (occupancy x CU count).
-hipError_t plan_launch(int N, bool window, bool use_dma, int device, LaunchInfo* li);
+hipError_t plan_launch(int N, int vid, bool window, bool use_dma, int device, LaunchInfo* li);
 
 // Fused unpack + FFT + |X|^2 accumulate over frames [0, nframes) of d_stream
-// (frame f = bytes [2N f, 2N (f+1))).  Writes li.grid*li.fpw partial spectra of
-// N doubles each to d_partial (every slot is written, zeros included).
+// (frame f = bytes [2N f, 2N (f+1))).  Writes one partial spectrum of N doubles
+// per workgroup to d_partial (every workgroup writes, zeros included).
 // `grid` is the number of workgroups to launch (<= the planned grid).
-hipError_t launch_fft_accum(int N, bool window, bool use_dma, const uint8_t* d_stream,
+hipError_t launch_fft_accum(int N, int vid, bool window, bool use_dma, const uint8_t* d_stream,
                             long nframes, const cf* d_twiddles, const float* d_window,
                             double* d_partial, int grid, hipStream_t stream, LaunchInfo* li);
 

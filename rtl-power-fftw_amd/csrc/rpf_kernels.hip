@@ -120,7 +120,7 @@ __device__ __forceinline__ void middle_passes(int t, cf* x,
 }
 
 template <class G, int WG, int OCC, bool WINDOW, bool DMA>
-__global__ __launch_bounds__(WG, (OCC * WG) / 256) void fft_accum_kernel(const uint8_t* __restrict__ stream,
+__global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __restrict__ stream,
                                                        long nframes,
                                                        const cf* __restrict__ twN,
                                                        const float* __restrict__ window,
@@ -176,13 +176,35 @@ __global__ __launch_bounds__(WG, (OCC * WG) / 256) void fft_accum_kernel(const u
         // this iteration's last reads by the sync at the top of the loop.
     }
 
-    // One partial spectrum per frame slot; every slot is written (zeros too).
-    double* out = partial + (static_cast<size_t>(blockIdx.x) * FPW + fs) * N;
+    // One partial spectrum per workgroup (the FPW frame slots are summed here);
+    // every workgroup writes its partial, zeros included.  The accumulators go
+    // through LDS (now free) so that the bin-scattered registers leave as fully
+    // coalesced 512-byte rows: stage at a padded bin index (one spare double per
+    // 16, conflict-free for the stride-16 bin pattern of bin_of), then stream out.
+    exchange_sync<true>();
+    double* const stage = reinterpret_cast<double*>(smem);          // [FPW][N + N/16]
+    constexpr int SN = N + N / 16;
+    static_assert(sizeof(double) * SN <= sizeof(cf) * G::LDS_CPX + 2 * N, "stage fits the slab");
 #pragma unroll
-    for (int a = 0; a < P; ++a) out[bin_of<G>(t, a)] = acc[a];
+    for (int a = 0; a < P; ++a) {
+        const int bin = bin_of<G>(t, a);
+        stage[fs * SN + bin + (bin >> 4)] = acc[a];
+    }
+    exchange_sync<true>();
+    double* out = partial + static_cast<size_t>(blockIdx.x) * N;
+    for (int bin = tid; bin < N; bin += WG) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < FPW; ++k) v += stage[k * SN + bin + (bin >> 4)];
+        out[bin] = v;
+    }
 }
 
-constexpr int RED_BINS = 16, RED_GROUPS = 16;
+// K3.  out[bin] = (accumulate ? out[bin] : 0) + sum over workgroup partials, in
+// a fixed order (bit-reproducible for a given grid): thread (g, b) sums the
+// partials g, g+16, g+32, ... of bin b with 8 independent loads in flight, then
+// the 16 group sums are added in group order.
+constexpr int RED_BINS = 16, RED_GROUPS = 16, RED_UNROLL = 8;
 
 __global__ __launch_bounds__(RED_BINS* RED_GROUPS) void reduce_kernel(
     const double* __restrict__ partial, int nslots, int N, double* __restrict__ out,
@@ -192,8 +214,19 @@ __global__ __launch_bounds__(RED_BINS* RED_GROUPS) void reduce_kernel(
     const int b = threadIdx.x % RED_BINS, g = threadIdx.x / RED_BINS;
     const int bin = blockIdx.x * RED_BINS + b;
     double s = 0.0;
-    if (bin < N)
-        for (int sl = g; sl < nslots; sl += RED_GROUPS) s += partial[static_cast<size_t>(sl) * N + bin];
+    if (bin < N) {
+        const double* p = partial + bin;
+        int sl = g;
+        for (; sl + (RED_UNROLL - 1) * RED_GROUPS < nslots; sl += RED_UNROLL * RED_GROUPS) {
+            double v[RED_UNROLL];
+#pragma unroll
+            for (int u = 0; u < RED_UNROLL; ++u)
+                v[u] = p[static_cast<size_t>(sl + u * RED_GROUPS) * N];
+#pragma unroll
+            for (int u = 0; u < RED_UNROLL; ++u) s += v[u];
+        }
+        for (; sl < nslots; sl += RED_GROUPS) s += p[static_cast<size_t>(sl) * N];
+    }
     red[g][b] = s;
     __syncthreads();
     if (g == 0 && bin < N) {
@@ -208,46 +241,49 @@ __global__ __launch_bounds__(RED_BINS* RED_GROUPS) void reduce_kernel(
 using KernelFn = void (*)(const uint8_t*, long, const cf*, const float*, double*);
 
 struct Variant {
-    int N, P, WG, fpw, lds_bytes;
+    int N, vid, P, WG, fpw, lds_bytes;
     KernelFn fn[2][2];   // [window][dma]
 };
 
-// OCC = workgroup-equivalents of 256 threads the register budget must admit per
-// CU (waves per SIMD).
-template <int N, int P, int OCC>
-Variant make_variant()
+// OCC (OCCW for the windowed kernels) = waves per SIMD the register budget
+// must admit (= resident workgroups per CU x WG/256).  vid = tuning variant (0 = the default for this N).
+template <int N, int P, int OCC, int OCCW = OCC>
+Variant make_variant(int vid)
 {
     using G = Geom<N, P>;
     constexpr int WG = G::T >= 256 ? G::T : 256;
     constexpr int FPW = WG / G::T;
     constexpr int LDS = FPW * (G::LDS_CPX * (int)sizeof(cf) + 2 * N);
-    return Variant{N, P, WG, FPW, LDS,
+    return Variant{N, vid, P, WG, FPW, LDS,
                    {{fft_accum_kernel<G, WG, OCC, false, false>,
                      fft_accum_kernel<G, WG, OCC, false, true>},
-                    {fft_accum_kernel<G, WG, OCC, true, false>,
-                     fft_accum_kernel<G, WG, OCC, true, true>}}};
+                    {fft_accum_kernel<G, WG, OCCW, true, false>,
+                     fft_accum_kernel<G, WG, OCCW, true, true>}}};
 }
 
 const Variant kVariants[] = {
-    make_variant<64, 8, 4>(),    make_variant<128, 8, 4>(),   make_variant<256, 8, 4>(),
-    make_variant<512, 8, 4>(),   make_variant<1024, 16, 2>(), make_variant<2048, 16, 2>(),
-    make_variant<4096, 16, 2>(), make_variant<8192, 16, 1>(),
+    make_variant<64, 8, 4>(0),    make_variant<128, 8, 4>(0),   make_variant<256, 8, 4>(0),
+    make_variant<512, 8, 4>(0),   make_variant<1024, 16, 3>(0), make_variant<2048, 16, 3>(0),
+    make_variant<4096, 16, 3, 2>(0), make_variant<8192, 16, 2>(0),
+    // tuning variants (RPF_FLAG_VARIANT(k))
+    make_variant<4096, 16, 2>(1), make_variant<4096, 8, 4>(2),  make_variant<4096, 8, 6>(3),
+    make_variant<512, 16, 3>(1),  make_variant<1024, 8, 4>(1),  make_variant<2048, 8, 4>(1),
 };
 
-const Variant* find_variant(int N)
+const Variant* find_variant(int N, int vid)
 {
     for (const Variant& v : kVariants)
-        if (v.N == N) return &v;
+        if (v.N == N && v.vid == vid) return &v;
     return nullptr;
 }
 
 }  // namespace
 
-bool kernel_supported(int N) { return find_variant(N) != nullptr; }
+bool kernel_supported(int N, int vid) { return find_variant(N, vid) != nullptr; }
 
-hipError_t plan_launch(int N, bool window, bool use_dma, int device, LaunchInfo* li)
+hipError_t plan_launch(int N, int vid, bool window, bool use_dma, int device, LaunchInfo* li)
 {
-    const Variant* v = find_variant(N);
+    const Variant* v = find_variant(N, vid);
     if (!v) return hipErrorInvalidValue;
     KernelFn fn = v->fn[window ? 1 : 0][use_dma ? 1 : 0];
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
@@ -268,11 +304,11 @@ hipError_t plan_launch(int N, bool window, bool use_dma, int device, LaunchInfo*
     return hipSuccess;
 }
 
-hipError_t launch_fft_accum(int N, bool window, bool use_dma, const uint8_t* d_stream,
+hipError_t launch_fft_accum(int N, int vid, bool window, bool use_dma, const uint8_t* d_stream,
                             long nframes, const cf* d_twiddles, const float* d_window,
                             double* d_partial, int grid, hipStream_t stream, LaunchInfo* li)
 {
-    const Variant* v = find_variant(N);
+    const Variant* v = find_variant(N, vid);
     if (!v || grid < 1) return hipErrorInvalidValue;
     KernelFn fn = v->fn[window ? 1 : 0][use_dma ? 1 : 0];
     hipLaunchKernelGGL(fn, dim3(grid), dim3(v->WG), v->lds_bytes, stream, d_stream, nframes,

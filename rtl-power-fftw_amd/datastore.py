@@ -147,6 +147,18 @@ class Datastore:
             ctypes.c_void_p(d_pwr_ptr), ctypes.c_void_p(hip_stream), ctypes.byref(done)))
         return done.value
 
+    def device_fused(self, d_stream_ptr, nbytes, repeats, hip_stream=0):
+        """K1 only (measurement hook, rpf_device_fused)."""
+        done = ctypes.c_int64()
+        self._check(self._lib.rpf_device_fused(self._handle, ctypes.c_void_p(d_stream_ptr), nbytes,
+                                               repeats, ctypes.c_void_p(hip_stream), ctypes.byref(done)))
+        return done.value
+
+    def device_reduce(self, d_pwr_ptr, hip_stream=0):
+        """K3 only (measurement hook, rpf_device_reduce)."""
+        self._check(self._lib.rpf_device_reduce(self._handle, ctypes.c_void_p(d_pwr_ptr),
+                                                ctypes.c_void_p(hip_stream)))
+
     def launch_info(self):
         vals = [ctypes.c_int() for _ in range(4)]
         self._check(self._lib.rpf_last_launch_info(self._handle, *[ctypes.byref(v) for v in vals]))

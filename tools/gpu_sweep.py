@@ -1,0 +1,62 @@
+"""Kernel-only timing (HIP events on the launch stream) + parity of every kernel
+variant.  Usage: python tools/gpu_sweep.py [N:variant ...]"""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import rtl_power_fftw_amd as rpf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "librpf_oracle.so"))
+c_u8p = ctypes.POINTER(ctypes.c_uint8); c_dp = ctypes.POINTER(ctypes.c_double); c_fp = ctypes.POINTER(ctypes.c_float)
+orc.rpf_oracle_accumulate.argtypes = [ctypes.c_int, c_fp, ctypes.c_int, c_u8p, ctypes.c_size_t, ctypes.c_int64, c_dp, ctypes.POINTER(ctypes.c_int64)]
+
+def oracle(N, buf, R, win=None, prec=64):
+    pwr = np.zeros(N); done = ctypes.c_int64()
+    w = win.ctypes.data_as(c_fp) if win is not None else None
+    assert orc.rpf_oracle_accumulate(N, w, prec, buf.ctypes.data_as(c_u8p), buf.size, R, pwr.ctypes.data_as(c_dp), ctypes.byref(done)) == 0
+    return pwr
+
+dev = torch.device("cuda:0")
+TOTAL = 4096 * 10000            # complex samples per launch (same bytes for every N)
+cases = sys.argv[1:] or ["4096:0", "4096:1", "4096:2", "4096:3", "512:0", "512:1", "1024:0", "1024:1",
+                         "2048:0", "2048:1", "8192:0", "64:0", "128:0", "256:0"]
+base = rpf.synth.noise_tones_iq(2, TOTAL)
+NB = 4
+bufs = [torch.from_numpy(base).to(dev)]
+bufs += [torch.roll(bufs[0], shifts=8192 * 37 * i) for i in range(1, NB)]
+s = torch.cuda.current_stream().cuda_stream
+for case in cases:
+    N, vid = (int(v) for v in case.split(":"))
+    R = TOTAL // N
+    for win in (False, True):
+        w = rpf.synth.hann_window(N) if win else None
+        try:
+            ds = rpf.Datastore(rpf.Params(N=N, window=win, repeats=R), w, flags=(vid << 8))
+        except rpf.RPFError as ex:
+            print("N=%d v=%d win=%d: %s" % (N, vid, win, ex)); continue
+        d_pwr = torch.zeros(N, dtype=torch.float64, device=dev)
+        # parity on the first 64 frames
+        RC = 64
+        ds.accumulate_device(bufs[0].data_ptr(), 2 * N * RC, RC, d_pwr.data_ptr(), s)
+        torch.cuda.synchronize()
+        t = oracle(N, base[: 2 * N * RC], RC, w)
+        err = float(np.max(np.abs(d_pwr.cpu().numpy() - t) / t))
+        for i in range(3):
+            ds.device_fused(bufs[i % NB].data_ptr(), 2 * N * R, R, s)
+        torch.cuda.synchronize()
+        K = 40
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(K):
+            ds.device_fused(bufs[i % NB].data_ptr(), 2 * N * R, R, s)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / K
+        e0.record()
+        for i in range(K):
+            ds.device_reduce(d_pwr.data_ptr(), s)
+        e1.record(); torch.cuda.synchronize()
+        msr = e0.elapsed_time(e1) / K
+        print("N=%5d v=%d win=%d  K1 %.4f ms  %.1f Gsample/s  %.0f GB/s (%.1f%% of 8 TB/s)  K3 %.4f ms  err-vs-f64 %.2e  %s"
+              % (N, vid, win, ms, TOTAL / ms / 1e6, 2 * TOTAL / ms / 1e6, 2 * TOTAL / ms / 1e6 / 80, msr, err, ds.launch_info()), flush=True)
+        ds.close()
