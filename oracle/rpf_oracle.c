@@ -17,15 +17,19 @@
 /* ------------------------------------------------------------------ FFT -- */
 
 #define REAL float
+#define WIDE double
 #define SUFFIX f32
 #include "rpf_oracle_fft.inc"
 #undef REAL
+#undef WIDE
 #undef SUFFIX
 
 #define REAL double
+#define WIDE long double
 #define SUFFIX f64
 #include "rpf_oracle_fft.inc"
 #undef REAL
+#undef WIDE
 #undef SUFFIX
 
 struct rpf_oracle_plan {

@@ -9,4 +9,4 @@ class over that C-ABI, the synthetic IQ source, and the output formatter.
 """
 from ._lib import RPFError, ReturnValue, build, lib_path, load  # noqa: F401
 from .datastore import Datastore, Params  # noqa: F401
-from . import synth  # noqa: F401
+from . import sharding, synth  # noqa: F401

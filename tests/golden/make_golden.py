@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz -- float64 ground truth for the hot path.
+
+The reference ships no golden vectors and cannot be built in this
+image (it needs fftw3/TCLAP/librtlsdr), so these fixtures are computed from the
+mathematical definition of the path (/root/reference/src/datastore.cxx:66-89):
+exact unpack arithmetic in float32 (integers, and one float32 rounding for the
+window product), then a complex128 numpy FFT and a float64 sum of |X|^2.
+Inputs come from the integer-only generators in rtl-power-fftw_amd/synth.py and
+are regenerated from their seed by the tests, so only the expected spectra are
+stored.  Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import rtl_power_fftw_amd as rpf  # noqa: E402
+
+CASES = [
+    # name, N, repeats, generator, seed, window
+    ("c1_n512_r100_uniform", 512, 100, "uniform", 1, False),       # BASELINE.json configs[0]
+    ("n512_r100_hann", 512, 100, "noise_tones", 11, True),
+    ("n4096_r64_noise", 4096, 64, "noise_tones", 2, False),        # head of config C2's stream
+    ("n4096_r64_hann", 4096, 64, "noise_tones", 2, True),          # head of config C3's stream
+    ("n64_r33_uniform", 64, 33, "uniform", 3, False),
+    ("n1024_r17_noise", 1024, 17, "noise_tones", 4, True),
+    ("n8192_r9_noise", 8192, 9, "noise_tones", 5, False),
+    ("n500_r20_uniform", 500, 20, "uniform", 6, False),            # man page's non-power-of-two example size
+    # config C4's size; noise only: at this N the weak tones of noise_tones would
+    # tower 3e4 x over the noise floor and no float32 FFT resolves the floor bins
+    # of such a frame to 1e-6
+    ("n262144_r2_uniform", 262144, 2, "uniform", 7, False),
+]
+
+
+def stream_for(gen, seed, nsamples):
+    if gen == "uniform":
+        return rpf.synth.uniform_iq(seed, nsamples)
+    return rpf.synth.noise_tones_iq(seed, nsamples)
+
+
+def truth(N, stream, repeats, window):
+    x = stream[: 2 * N * repeats].astype(np.float32).reshape(repeats, N, 2) - np.float32(127.0)
+    sign = (1 - 2 * (np.arange(N) % 2)).astype(np.float32)
+    x = x * sign[None, :, None]
+    if window is not None:
+        x = x * window[None, :, None]          # float32 product, one rounding
+    z = x[..., 0].astype(np.float64) + 1j * x[..., 1].astype(np.float64)
+    spec = np.fft.fft(z, axis=1)
+    return (spec.real ** 2 + spec.imag ** 2).sum(axis=0)
+
+
+def main():
+    for name, N, R, gen, seed, win in CASES:
+        stream = stream_for(gen, seed, N * R)
+        window = rpf.synth.hann_window(N) if win else None
+        pwr = truth(N, stream, R, window)
+        out = dict(N=N, repeats=R, generator=gen, seed=seed, pwr=pwr,
+                   stream_crc=np.uint64(int(np.bitwise_xor.reduce(stream.view(np.uint8).astype(np.uint64) * np.arange(1, stream.size + 1, dtype=np.uint64)))))
+        if window is not None:
+            out["window"] = window
+        if N > 16384:
+            # keep the fixture small: every 64th bin plus the total
+            out["pwr"] = pwr[::64].copy()
+            out["stride"] = 64
+            out["total"] = pwr.sum()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, N, R, "sum %.6e" % pwr.sum())
+
+
+if __name__ == "__main__":
+    main()

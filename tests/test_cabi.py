@@ -1,0 +1,76 @@
+"""The C-ABI library loads and exports exactly what include/rpf_engine.h declares;
+argument validation works without a GPU; without a device the engine fails loudly
+(no CPU fallback).  (-m "not gpu")"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import rtl_power_fftw_amd as rpf
+from rtl_power_fftw_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rpf_engine.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rpf_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_symbols() == sorted(_lib.symbol_names())
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib.lib_path())
+    for name in _declared_symbols():
+        assert hasattr(lib, name), name
+    assert rpf.load().rpf_abi_version() == 1
+
+
+def test_supported_sizes():
+    lib = rpf.load()
+    for n in (64, 128, 256, 512, 1024, 2048, 4096, 8192):
+        assert lib.rpf_supported_n(n) == 1
+    for n in (0, 2, 500, 513, 16384):
+        assert lib.rpf_supported_n(n) == 0
+
+
+def test_invalid_arguments_map_to_reference_exit_codes():
+    # exit codes of /root/reference/src/exceptions.h:25-34
+    with pytest.raises(rpf.RPFError) as e:
+        rpf.Datastore(rpf.Params(N=500))                      # no kernel for this size
+    assert e.value.retval == rpf.ReturnValue.InvalidArgument
+    with pytest.raises(rpf.RPFError) as e:
+        rpf.Datastore(rpf.Params(N=511))                      # odd (params.cxx:150-155 bumps it upstream)
+    assert e.value.retval == rpf.ReturnValue.InvalidArgument
+    with pytest.raises(rpf.RPFError) as e:
+        rpf.Datastore(rpf.Params(N=512, buffers=0))
+    assert e.value.retval == rpf.ReturnValue.InvalidArgument
+    with pytest.raises(rpf.RPFError) as e:
+        rpf.Datastore(rpf.Params(N=512, window=True), window_values=np.ones(5, dtype=np.float32))
+    assert e.value.retval == rpf.ReturnValue.InvalidInput
+    with pytest.raises(rpf.RPFError) as e:
+        rpf.Datastore(rpf.Params(N=4096), flags=(200 << 8))    # unknown tuning variant
+    assert e.value.retval == rpf.ReturnValue.InvalidArgument
+
+
+def test_no_device_means_hardware_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(rpf.RPFError) as e:
+        rpf.Datastore(rpf.Params(N=4096))
+    assert e.value.retval == rpf.ReturnValue.HardwareError
+    assert "no CPU path" in str(e.value)
+
+
+def test_product_does_not_link_the_oracle():
+    import subprocess
+    out = subprocess.run(["readelf", "-d", _lib.lib_path()], capture_output=True, text=True).stdout
+    assert "rpf_oracle" not in out and "rpf_emul" not in out
+    syms = subprocess.run(["nm", "-D", _lib.lib_path()], capture_output=True, text=True).stdout
+    assert "rpf_oracle" not in syms
