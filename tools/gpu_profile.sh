@@ -1,0 +1,20 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): bench.py, then the same command under
+# rocprofv3 --kernel-trace --stats, then PMC passes (each in its own run, as the
+# HBM/rocprofv3 section of MI355X_MICROARCH.md prescribes).  Output under
+# gpurun_out/$1/ ; summaries are copied to profiles/ by tools/summarize_profile.py.
+set -u
+TAG=${1:-r01}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+cat $OUT/bench.json
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 400 --warmup 40 --no-cpu-baseline"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o c2 -- $BENCH > $OUT/trace.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o c2 -- $BENCH > $OUT/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o c2 -- $BENCH > $OUT/pmc_write.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/pmc_sq -o c2 -- $BENCH > $OUT/pmc_sq.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_lds -o c2 -- $BENCH > $OUT/pmc_lds.log 2>&1
+ls -R $OUT | head -40

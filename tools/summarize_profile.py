@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/<tag>/ (written by tools/gpu_profile.sh on the GPU box)
+into the tracked files under profiles/:
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (verbatim)
+  profiles/<tag>_counters.json      per-launch means of the PMC passes for K1 / K3
+  profiles/<tag>_bench.json         the bench.py line of the same run
+  profiles/traffic.json             HBM bytes per K1 launch, read by bench.py
+HBM bytes follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are
+collected in separate --pmc passes, are in KiB, and on gfx950 FETCH_SIZE reports
+half the bytes of a wide coalesced read -- calibrated in the same run on
+torch's roll kernel, which reads exactly 81 920 000 B per launch."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+shutil.copy(os.path.join(src, "trace", "c2_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, tag + "_bench.json"))
+
+
+def means(path, full_grid_only=True):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        name = r["Kernel_Name"]
+        if "fft_accum_kernel" in name:
+            k = "K1_fft_accum"
+            if full_grid_only and int(r["Grid_Size"]) < 768 * 256:
+                continue
+        elif "reduce_kernel" in name:
+            k = "K3_reduce"
+        elif "roll_cuda_kernel" in name:
+            k = "calib_roll_81920000B"
+        else:
+            continue
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+
+
+out = {}
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
+    p = os.path.join(src, sub, "c2_counter_collection.csv")
+    if os.path.exists(p):
+        for k, d in means(p).items():
+            out.setdefault(k, {}).update(d)
+
+calib = out.get("calib_roll_81920000B", {})
+fetch_factor = None
+if "FETCH_SIZE" in calib:
+    fetch_factor = 81920000.0 / (calib["FETCH_SIZE"] * 1024.0)
+    out["fetch_size_calibration"] = {
+        "known_bytes": 81920000, "FETCH_SIZE_KiB": calib["FETCH_SIZE"], "bytes_per_reported_byte": fetch_factor,
+        "note": "MI355X_MICROARCH.md: FETCH_SIZE reads 1/2 of a wide coalesced stream on gfx950; factor applied = 2"}
+k1 = out.get("K1_fft_accum", {})
+traffic = {}
+if "FETCH_SIZE" in k1:
+    traffic["fft_accum_c2_fetch_bytes_per_launch"] = k1["FETCH_SIZE"] * 1024.0 * 2.0
+if "WRITE_SIZE" in k1:
+    traffic["fft_accum_c2_write_bytes_per_launch"] = k1["WRITE_SIZE"] * 1024.0
+if traffic:
+    traffic["fft_accum_c2_hbm_bytes_per_launch"] = sum(traffic.values())
+    traffic["source"] = "profiles/%s_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x2 per MI355X_MICROARCH.md)" % tag
+    json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(dst, tag + "_counters.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
+print(json.dumps(traffic, indent=1))
