@@ -102,7 +102,7 @@ struct Geom {
     static constexpr int LDS_CPX = N + N / P;           // padded complex slots per frame
     static_assert((1 << LOG2N) == N && (1 << LOG2P) == P, "N and P must be powers of two");
     static_assert(NPASS >= 2, "need at least two passes (N > P)");
-    static_assert(T % 2 == 0, "T must be even so that (-1)^n is a per-thread constant");
+    static_assert(T % 8 == 0, "T even: (-1)^n is a per-thread constant; T % 8: 16-byte raw pieces");
     static_assert(P % 8 == 0, "a thread stages 2P raw bytes in 16-byte pieces");
 
     // sub-FFT length entering pass J (1-based): L_{J-1}
@@ -255,9 +255,6 @@ struct Dft<16> {
 };
 
 // ------------------------------------------------------------------ phases --
-// Unpack P samples of one frame for pass 1 (datastore.cxx:73-77).  `raw` points
-// at the frame's 2N interleaved bytes.  sgn = (-1)^t (n = t + T a and T is even).
-// wsgn: per-register window values already multiplied by sgn, or nullptr.
 // u8 -> f32 without a (half-rate) v_cvt: OR the byte into the mantissa of 2^23,
 // i.e. bits 0x4B0000bb are the float 8388608 + b exactly.
 RPF_HD float byte_plus_2p23(uint32_t b)
@@ -266,15 +263,34 @@ RPF_HD float byte_plus_2p23(uint32_t b)
 }
 constexpr float kTwo23 = 8388608.0f;
 
+// Raw-byte staging is wavefront-local: a wave stages exactly the samples its own
+// 64 threads unpack, "a-major": bytes [128 a, 128 a + 128) of the wave's 128*P-byte
+// raw area hold sample n = t + T a of its 64 threads, so lane l reads its P samples
+// at 2 l + 128 a and no workgroup barrier is needed between staging and unpack.
+// raw_source maps byte j of that area back to the stream: which of the
+// workgroup's frame slots, and which byte of that frame.  16-byte pieces (j % 16
+// == 0) are contiguous and 16-byte aligned in the source because T % 8 == 0.
+constexpr int kRawChunk = 128;
+template <class G>
+RPF_HD void raw_source(int wave_in_wg, int j, int* slot, int* byte_in_frame)
+{
+    const int a = j / kRawChunk;
+    const int tid = wave_in_wg * 64 + ((j % kRawChunk) >> 1);
+    *slot = tid / G::T;
+    *byte_in_frame = 2 * (tid % G::T + G::T * a) + (j & 1);
+}
+
+// Unpack the P samples of one thread (datastore.cxx:73-77).  `lane_raw` points at
+// this lane's column of its wave's raw area.  sgn = (-1)^t (n = t + T a, T even).
+// wsgn: per-register window values already multiplied by sgn (WINDOW only).
 template <class G, bool WINDOW>
-RPF_HD void phase_unpack(int t, const uint8_t* raw, float sgn, const float* wsgn, cf* x)
+RPF_HD void phase_unpack(const uint8_t* lane_raw, float sgn, const float* wsgn, cf* x)
 {
     // (2^23 + v) * sgn - (2^23 + 127) * sgn = (v - 127) * sgn, every step exact
     const float off = -(kTwo23 + 127.0f) * sgn;
 #pragma unroll
     for (int a = 0; a < G::P; ++a) {
-        const int n = t + G::T * a;
-        const uint32_t iq = *reinterpret_cast<const uint16_t*>(raw + 2 * n);
+        const uint32_t iq = *reinterpret_cast<const uint16_t*>(lane_raw + kRawChunk * a);
         const cf f = cf{byte_plus_2p23(iq & 0xffu), byte_plus_2p23(iq >> 8)};
         if constexpr (WINDOW) {
             // (v - 127) is exact, * (+-w) rounds once: same value as the reference

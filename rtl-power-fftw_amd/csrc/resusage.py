@@ -13,6 +13,6 @@ for l in sys.stdin:
     if m and cur:
         d[m.group(1).strip()] = m.group(2)
         if 'LDS Size' in m.group(1):
-            g = re.search(r'GeomILi(\d+)ELi(\d+)EEELi(\d+)ELi(\d+)ELb(\d)ELb(\d)', cur)
-            tag = 'N=%s P=%s WG=%s OCC=%s win=%s dma=%s' % g.groups() if g else cur[:48]
+            g = re.search(r'GeomILi(\d+)ELi(\d+)EEELi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)', cur)
+            tag = 'N=%s P=%s WG=%s OCC=%s win=%s dma=%s dbuf=%s' % g.groups() if g else cur[:48]
             print(tag, {k: d.get(k) for k in ('VGPRs', 'AGPRs', 'ScratchSize', 'Occupancy', 'VGPRs Spill')})

@@ -54,31 +54,28 @@ __device__ __forceinline__ void exchange_sync()
 using gptr_t = const __attribute__((address_space(1))) void*;
 using lptr_t = __attribute__((address_space(3))) void*;
 
-// Stage the raw bytes of the frames this workgroup handles in iteration `fb`
-// (fb = frame index of slot 0).  Wave w, piece i moves the 1 KiB
-// [ (w*PIECES+i)*1024, +1024 ) of the workgroup's raw area, lane l the 16 bytes
-// at +16 l -- i.e. a wave only ever stages bytes of its own frame slot(s).
+// Stage the raw bytes this wavefront will unpack in the iteration whose slot-0
+// frame is `fb` (wave-local, a-major layout: fft_core.h raw_source).  P/8
+// instructions per wave, each moving 64 lanes x 16 B = eight 128-byte rows.
 template <class G, bool DMA>
 __device__ __forceinline__ void stage_raw(const uint8_t* __restrict__ stream, long fb,
-                                          long nframes, uint8_t* raw_base, int tid)
+                                          long nframes, uint8_t* wave_raw, int wave, int lane)
 {
     constexpr int PIECES = G::P / 8;
     constexpr int FRAME_BYTES = 2 * G::N;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-        const int wave_off = (wave * PIECES + i) * 1024;
-        const int B = wave_off + lane * 16;
-        const int slot = B / FRAME_BYTES, off = B % FRAME_BYTES;
+        const int j = i * 1024 + lane * 16;
+        int slot, off;
+        raw_source<G>(wave, j, &slot, &off);
         const long f = fb + slot;
         if (f < nframes) {
             const uint8_t* src = stream + f * FRAME_BYTES + off;
             if constexpr (DMA) {
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(raw_base + wave_off), 16, 0,
-                                                 0);
+                // LDS address = wave-uniform base + 16 * lane (added by the hardware)
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wave_raw + i * 1024), 16, 0, 0);
             } else {
-                *reinterpret_cast<uint4*>(raw_base + B) = *reinterpret_cast<const uint4*>(src);
+                *reinterpret_cast<uint4*>(wave_raw + j) = *reinterpret_cast<const uint4*>(src);
             }
         }
     }
@@ -96,49 +93,49 @@ __device__ __forceinline__ void load_twiddles(int t, const cf* __restrict__ twN,
 }
 
 // Passes J .. NPASS-1: [fetch] -> radix-P butterfly -> twiddle -> store -> sync.
-// Pass J > 1 reads and writes the same LDS slots per thread; the pass-1 store
-// is separated from the previous frame's last reads by the sync at the top of
-// the frame loop.  The exchange after pass J stays inside groups of L_J
-// threads, so it needs a workgroup barrier only if L_J > 64.
-template <class G, bool DMA, int J>
+// Pass J > 1 reads and writes the same LDS slots per thread.  The exchange after
+// pass J stays inside groups of L_J threads, so it needs a workgroup barrier
+// only if L_J > 64.
+template <class G, int J>
 __device__ __forceinline__ void middle_passes(int t, cf* x,
-                                              const cf (&tw)[G::NPASS - 1][G::P - 1], cf* slab,
-                                              const uint8_t* __restrict__ stream, long fb_next,
-                                              long nframes, uint8_t* raw_base, int tid)
+                                              const cf (&tw)[G::NPASS - 1][G::P - 1], cf* slab)
 {
     if constexpr (J < G::NPASS) {
         if constexpr (J > 1) phase_fetch<G, J>(t, x, slab);
         phase_butterfly_twiddle<G>(x, tw[J - 1]);
         phase_store<G, J>(t, x, slab);
         exchange_sync<(G::Lcur(J) > 64)>();
-        if constexpr (J == 1) {
-            // every raw read of this frame is done: stage the next frame
-            if (fb_next < nframes) stage_raw<G, DMA>(stream, fb_next, nframes, raw_base, tid);
-        }
-        middle_passes<G, DMA, J + 1>(t, x, tw, slab, stream, fb_next, nframes, raw_base, tid);
+        middle_passes<G, J + 1>(t, x, tw, slab);
     }
 }
 
-template <class G, int WG, int OCC, bool WINDOW, bool DMA>
+// DBUF: two slabs used alternately.  With one slab the pass-1 store of frame f+1
+// must wait (workgroup barrier at the top of the loop) until every wave has
+// finished reading frame f's slab; with two, the single barrier after the pass-1
+// store orders both hazards and a frame costs one s_barrier instead of two, at
+// the price of LDS (fewer resident workgroups).
+template <class G, int WG, int OCC, bool WINDOW, bool DMA, bool DBUF>
 __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __restrict__ stream,
-                                                       long nframes,
-                                                       const cf* __restrict__ twN,
-                                                       const float* __restrict__ window,
-                                                       double* __restrict__ partial)
+                                                            long nframes,
+                                                            const cf* __restrict__ twN,
+                                                            const float* __restrict__ window,
+                                                            double* __restrict__ partial)
 {
     constexpr int P = G::P, T = G::T, N = G::N, NPASS = G::NPASS;
     constexpr int FPW = WG / T;
+    constexpr int NSLAB = DBUF ? 2 : 1;
     constexpr bool BLOCK_SYNC = (T > 64);
     static_assert(WG % T == 0 && WG % 64 == 0, "");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cf* const slab_base = reinterpret_cast<cf*>(smem);                      // [FPW][LDS_CPX]
-    uint8_t* const raw_base = smem + FPW * G::LDS_CPX * sizeof(cf);        // [FPW][2N]
+    cf* const slab_base = reinterpret_cast<cf*>(smem);                        // [NSLAB][FPW][LDS_CPX]
+    uint8_t* const raw_base = smem + NSLAB * FPW * G::LDS_CPX * sizeof(cf);  // [WG/64][128 P]
 
     const int tid = threadIdx.x;
     const int fs = tid / T, t = tid % T;
-    cf* const slab = slab_base + fs * G::LDS_CPX;
-    const uint8_t* const raw = raw_base + fs * 2 * N;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    uint8_t* const wave_raw = raw_base + wave * (kRawChunk * P);
+    const uint8_t* const lane_raw = wave_raw + 2 * lane;
 
     // Loop-invariant per-thread constants: twiddles, sign, window.
     cf tw[NPASS - 1][P - 1];
@@ -155,25 +152,27 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
 
     const long stride = static_cast<long>(gridDim.x) * FPW;
     long fb = static_cast<long>(blockIdx.x) * FPW;
-    if (fb < nframes) stage_raw<G, DMA>(stream, fb, nframes, raw_base, tid);
+    if (fb < nframes) stage_raw<G, DMA>(stream, fb, nframes, wave_raw, wave, lane);
 
-    for (; fb < nframes; fb += stride) {
+    for (int it = 0; fb < nframes; fb += stride, ++it) {
         const bool active = (fb + fs) < nframes;
+        cf* const slab = slab_base + ((DBUF ? (it & 1) : 0) * FPW + fs) * G::LDS_CPX;
         cf x[P];
 
-        // raw bytes of this frame have landed
+        // this wave's raw bytes have landed (they are staged by the wave itself)
         if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        exchange_sync<BLOCK_SYNC>();
-        phase_unpack<G, WINDOW>(t, raw, sgn, wsgn, x);
+        exchange_sync<false>();
+        phase_unpack<G, WINDOW>(lane_raw, sgn, wsgn, x);
+        exchange_sync<false>();
+        // the raw reads are consumed: stage the next frame while this one computes
+        if (fb + stride < nframes) stage_raw<G, DMA>(stream, fb + stride, nframes, wave_raw, wave, lane);
 
-        // passes 1 .. NPASS-1: butterfly, twiddle, exchange (+ prefetch of the
-        // next frame's raw bytes once this frame's have all been read)
-        middle_passes<G, DMA, 1>(t, x, tw, slab, stream, fb + stride, nframes, raw_base, tid);
+        // single slab: every wave must be done with the previous frame's slab
+        if constexpr (!DBUF) exchange_sync<BLOCK_SYNC>();
+        middle_passes<G, 1>(t, x, tw, slab);
         phase_fetch<G, NPASS>(t, x, slab);
         phase_last<G>(x);
         if (active) phase_accumulate(x, acc, P);
-        // The next iteration's first LDS write (pass-1 store) is separated from
-        // this iteration's last reads by the sync at the top of the loop.
     }
 
     // One partial spectrum per workgroup (the FPW frame slots are summed here);
@@ -184,7 +183,7 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
     exchange_sync<true>();
     double* const stage = reinterpret_cast<double*>(smem);          // [FPW][N + N/16]
     constexpr int SN = N + N / 16;
-    static_assert(sizeof(double) * SN <= sizeof(cf) * G::LDS_CPX + 2 * N, "stage fits the slab");
+    static_assert(sizeof(double) * SN <= sizeof(cf) * G::LDS_CPX + 2 * N, "stage fits the LDS");
 #pragma unroll
     for (int a = 0; a < P; ++a) {
         const int bin = bin_of<G>(t, a);
@@ -246,28 +245,30 @@ struct Variant {
 };
 
 // OCC (OCCW for the windowed kernels) = waves per SIMD the register budget
-// must admit (= resident workgroups per CU x WG/256).  vid = tuning variant (0 = the default for this N).
-template <int N, int P, int OCC, int OCCW = OCC>
+// must admit (= resident workgroups per CU x WG/256).  vid = tuning variant
+// (0 = the default for this N).
+template <int N, int P, int OCC, int OCCW = OCC, bool DBUF = false>
 Variant make_variant(int vid)
 {
     using G = Geom<N, P>;
     constexpr int WG = G::T >= 256 ? G::T : 256;
     constexpr int FPW = WG / G::T;
-    constexpr int LDS = FPW * (G::LDS_CPX * (int)sizeof(cf) + 2 * N);
+    constexpr int LDS = FPW * ((DBUF ? 2 : 1) * G::LDS_CPX * (int)sizeof(cf) + 2 * N);
     return Variant{N, vid, P, WG, FPW, LDS,
-                   {{fft_accum_kernel<G, WG, OCC, false, false>,
-                     fft_accum_kernel<G, WG, OCC, false, true>},
-                    {fft_accum_kernel<G, WG, OCCW, true, false>,
-                     fft_accum_kernel<G, WG, OCCW, true, true>}}};
+                   {{fft_accum_kernel<G, WG, OCC, false, false, DBUF>,
+                     fft_accum_kernel<G, WG, OCC, false, true, DBUF>},
+                    {fft_accum_kernel<G, WG, OCCW, true, false, DBUF>,
+                     fft_accum_kernel<G, WG, OCCW, true, true, DBUF>}}};
 }
 
 const Variant kVariants[] = {
-    make_variant<64, 8, 4>(0),    make_variant<128, 8, 4>(0),   make_variant<256, 8, 4>(0),
-    make_variant<512, 8, 4>(0),   make_variant<1024, 16, 3>(0), make_variant<2048, 16, 3>(0),
+    make_variant<64, 8, 4>(0),       make_variant<128, 8, 4>(0),   make_variant<256, 8, 4>(0),
+    make_variant<512, 8, 4>(0),      make_variant<1024, 16, 3>(0), make_variant<2048, 16, 3>(0),
     make_variant<4096, 16, 3, 2>(0), make_variant<8192, 16, 2>(0),
     // tuning variants (RPF_FLAG_VARIANT(k))
-    make_variant<4096, 16, 2>(1), make_variant<4096, 8, 4>(2),  make_variant<4096, 8, 6>(3),
-    make_variant<512, 16, 3>(1),  make_variant<1024, 8, 4>(1),  make_variant<2048, 8, 4>(1),
+    make_variant<4096, 16, 2, 2, true>(1), make_variant<4096, 8, 4>(2), make_variant<4096, 8, 4, 4, true>(3),
+    make_variant<512, 16, 3>(1),           make_variant<1024, 8, 4>(1), make_variant<2048, 8, 4>(1),
+    make_variant<2048, 16, 2, 2, true>(2), make_variant<8192, 16, 2, 2, true>(1),
 };
 
 const Variant* find_variant(int N, int vid)

@@ -64,15 +64,27 @@ int run(const float* window, const uint8_t* stream, long nframes, double* pwr)
     // poison the padding slots: nothing may ever read them
     for (auto& c : slab) c = {NAN, NAN};
 
+    // One emulated "workgroup" = max(T, 64) threads: whole wavefronts stage the raw
+    // bytes (raw_source), exactly as the kernel does; frames beyond the first
+    // slot of a wave (T < 64) are staged too but only slot 0 is computed here.
+    constexpr int WAVES = T >= 64 ? T / 64 : 1;
+    std::vector<uint8_t> raw(WAVES * rpf::kRawChunk * P);
     for (long f = 0; f < nframes; ++f) {
-        const uint8_t* raw = stream + (size_t)f * 2 * N;
+        const uint8_t* frame = stream + (size_t)f * 2 * N;
+        for (int w = 0; w < WAVES; ++w)
+            for (int j = 0; j < rpf::kRawChunk * P; ++j) {
+                int slot, off;
+                rpf::raw_source<G>(w, j, &slot, &off);
+                raw[w * rpf::kRawChunk * P + j] = slot == 0 ? frame[off] : 0;
+            }
         for (int t = 0; t < T; ++t) {
             const float sgn = (t & 1) ? -1.0f : 1.0f;
             float wsgn[P];
             if (window)
                 for (int a = 0; a < P; ++a) wsgn[a] = window[t + T * a] * sgn;
-            if (window) rpf::phase_unpack<G, true>(t, raw, sgn, wsgn, regs[t].data());
-            else rpf::phase_unpack<G, false>(t, raw, sgn, wsgn, regs[t].data());
+            const uint8_t* lane_raw = raw.data() + (t / 64) * rpf::kRawChunk * P + 2 * (t % 64);
+            if (window) rpf::phase_unpack<G, true>(lane_raw, sgn, wsgn, regs[t].data());
+            else rpf::phase_unpack<G, false>(lane_raw, sgn, wsgn, regs[t].data());
         }
         middle<G, 1>(regs, slab, tws);
         for (int t = 0; t < T; ++t) {
