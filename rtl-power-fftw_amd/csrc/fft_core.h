@@ -130,20 +130,23 @@ RPF_HD int elem_of(int t, int a)
 // Spectrum bin of the value that ends the last pass in register a of thread t.
 // Element e = sum_j d_j L_j (digits d_1..d_{NPASS-1} in [0,P), last digit in
 // [0,RLAST)) holds X[d_1 + P d_2 + P^2 d_3 + ...].
+template <class G, int J = 1>
+RPF_HD int bin_digits(int e, int weight)
+{
+    // digits from the most significant (d_1, weight 1) down; compile-time pass
+    // recursion so that every divisor is a constant power of two
+    if constexpr (J < G::NPASS) {
+        constexpr int L = G::N / ipow(G::P, J);     // L_J
+        const int d = e / L;
+        return d * weight + bin_digits<G, J + 1>(e - d * L, weight * G::P);
+    } else {
+        return e * weight;
+    }
+}
 template <class G>
 RPF_HD int bin_of(int t, int a)
 {
-    int e = G::P * t + a;
-    int bin = 0, weight = 1;
-    // digits from the most significant (d_1, weight 1) down
-    for (int j = 1; j < G::NPASS; ++j) {
-        const int L = G::N / ipow(G::P, j);     // L_j
-        const int d = e / L;
-        e -= d * L;
-        bin += d * weight;
-        weight *= G::P;
-    }
-    return bin + e * weight;
+    return bin_digits<G>(G::P * t + a, 1);
 }
 
 // ------------------------------------------------------- constant twiddles --

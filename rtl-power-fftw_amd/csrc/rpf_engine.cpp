@@ -81,6 +81,9 @@ struct rpf_engine {
     // device side
     hipStream_t copy_stream = nullptr, compute_stream = nullptr;
     rpf::cf* d_twiddles = nullptr;
+    bool fourstep = false;                // N handled by rpf_fourstep.hip
+    rpf::cf* d_tw_sub = nullptr;          // four-step: W_512 table of the sub-transforms
+    rpf::cf* d_scratch = nullptr;         // four-step: intermediate Y
     float* d_window = nullptr;
     double* d_partial = nullptr;
     double* d_pwr = nullptr;
@@ -89,6 +92,7 @@ struct rpf_engine {
     hipEvent_t copy_done = nullptr;
     rpf::LaunchInfo plan;                 // resident grid for this N
     rpf::LaunchInfo last;                 // last launch
+    int last_slots = 0;                   // partial spectra left by the last transform
 
     mutable std::string last_error;
 };
@@ -110,19 +114,40 @@ int fail(rpf_engine* e, int rc, const std::string& msg)
                         std::string(#call) + ": " + hipGetErrorString(err__));           \
     } while (0)
 
-// Launch the fused kernel + reduce for `nframes` frames starting at d_frames.
-int launch_frames(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, double* d_out,
-                  bool accumulate, hipStream_t stream)
+// Enqueue K1 (or the four-step pair K2a/K2b) for `nframes` frames starting at
+// d_frames; leaves *nslots partial spectra in e->d_partial.
+int launch_transform(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, hipStream_t stream,
+                     int* nslots)
 {
-    if (nframes <= 0) return RPF_OK;
-    const bool aligned = (reinterpret_cast<uintptr_t>(d_frames) % 16) == 0;
-    const bool dma = e->use_dma && aligned;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(d_frames);
+    if (e->fourstep) {
+        const bool dma = e->use_dma && (addr % 4) == 0;
+        HIP_TRY(e, rpf::launch_fourstep(e->N, e->has_window, dma, d_frames, nframes, e->d_tw_sub,
+                                        e->d_twiddles, e->d_window, e->d_scratch, e->d_partial,
+                                        e->plan.grid, stream));
+        e->last = e->plan;
+        *nslots = rpf::fourstep_partial_slots(e->N);
+        return RPF_OK;
+    }
+    const bool dma = e->use_dma && (addr % 16) == 0;
     const int64_t wanted = (nframes + e->plan.fpw - 1) / e->plan.fpw;
     const int grid = static_cast<int>(std::min<int64_t>(e->plan.grid, wanted));
     HIP_TRY(e, rpf::launch_fft_accum(e->N, e->variant, e->has_window, dma, d_frames, nframes, e->d_twiddles,
                                      e->d_window, e->d_partial, grid, stream, &e->last));
-    HIP_TRY(e, rpf::launch_reduce(e->d_partial, grid, e->N, d_out, accumulate,
-                                  stream));
+    *nslots = grid;
+    return RPF_OK;
+}
+
+// Transform + reduce for `nframes` frames starting at d_frames.
+int launch_frames(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, double* d_out,
+                  bool accumulate, hipStream_t stream)
+{
+    if (nframes <= 0) return RPF_OK;
+    int nslots = 0;
+    int rc = launch_transform(e, d_frames, nframes, stream, &nslots);
+    if (rc != RPF_OK) return rc;
+    e->last_slots = nslots;
+    HIP_TRY(e, rpf::launch_reduce(e->d_partial, nslots, e->N, d_out, accumulate, stream));
     return RPF_OK;
 }
 
@@ -230,6 +255,8 @@ void worker_main(rpf_engine* e)
 void release_device(rpf_engine* e)
 {
     if (e->d_twiddles) (void)hipFree(e->d_twiddles);
+    if (e->d_tw_sub) (void)hipFree(e->d_tw_sub);
+    if (e->d_scratch) (void)hipFree(e->d_scratch);
     if (e->d_window) (void)hipFree(e->d_window);
     if (e->d_partial) (void)hipFree(e->d_partial);
     if (e->d_pwr) (void)hipFree(e->d_pwr);
@@ -250,7 +277,7 @@ extern "C" {
 
 int rpf_abi_version(void) { return RPF_ABI_VERSION; }
 
-int rpf_supported_n(int N) { return rpf::kernel_supported(N) ? 1 : 0; }
+int rpf_supported_n(int N) { return (rpf::kernel_supported(N) || rpf::fourstep_supported(N)) ? 1 : 0; }
 
 const char* rpf_last_global_error(void) { return g_last_error.c_str(); }
 
@@ -264,10 +291,11 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT,
                     "Number of bins must be a positive even number.");
     const int variant = static_cast<int>((cfg->flags >> 8) & 0xffu);
-    if (!rpf::kernel_supported(cfg->N, variant))
+    const bool fourstep = rpf::fourstep_supported(cfg->N) && variant == 0;
+    if (!fourstep && !rpf::kernel_supported(cfg->N, variant))
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT,
                     "No gfx950 kernel for " + std::to_string(cfg->N) +
-                        " bins in this build (supported: powers of two 64..8192).");
+                        " bins in this build (supported: powers of two 64..8192, and 262144).");
     if (cfg->n_buffers < 1)
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT, "Argument to 'buffers' must be a positive number.");
     if (cfg->buffer_capacity < 2 || (cfg->buffer_capacity % 2) != 0)
@@ -292,6 +320,7 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
     e->flags = cfg->flags;
     e->use_dma = !(cfg->flags & RPF_FLAG_NO_LDS_DMA);
     e->variant = variant;
+    e->fourstep = fourstep;
     e->queue_histogram.assign(e->n_buffers + 1, 0);
     e->pwr.assign(e->N, 0.0);
 
@@ -322,14 +351,23 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         CREATE_TRY(hipMalloc(&e->d_window, sizeof(float) * e->N));
         CREATE_TRY(hipMemcpy(e->d_window, cfg->window, sizeof(float) * e->N, hipMemcpyHostToDevice));
     }
-    CREATE_TRY(rpf::plan_launch(e->N, e->variant, e->has_window, true, e->device, &e->plan));
-    {
+    size_t partial_slots = 0;
+    if (e->fourstep) {
+        CREATE_TRY(rpf::fourstep_prepare(e->N, e->device, &e->plan));
+        std::vector<rpf::cf> tws;
+        rpf::make_twiddles(512, tws);
+        CREATE_TRY(hipMalloc(&e->d_tw_sub, sizeof(rpf::cf) * tws.size()));
+        CREATE_TRY(hipMemcpy(e->d_tw_sub, tws.data(), sizeof(rpf::cf) * tws.size(), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc(&e->d_scratch, rpf::fourstep_scratch_bytes(e->N)));
+        partial_slots = rpf::fourstep_partial_slots(e->N);
+    } else {
+        CREATE_TRY(rpf::plan_launch(e->N, e->variant, e->has_window, true, e->device, &e->plan));
         rpf::LaunchInfo tmp;
         CREATE_TRY(rpf::plan_launch(e->N, e->variant, e->has_window, false, e->device, &tmp));
         e->plan.grid = std::min(e->plan.grid, tmp.grid);
+        partial_slots = e->plan.grid;
     }
-    CREATE_TRY(hipMalloc(&e->d_partial,
-                         sizeof(double) * e->N * static_cast<size_t>(e->plan.grid)));
+    CREATE_TRY(hipMalloc(&e->d_partial, sizeof(double) * e->N * partial_slots));
     CREATE_TRY(hipMalloc(&e->d_pwr, sizeof(double) * e->N));
     CREATE_TRY(hipMemset(e->d_pwr, 0, sizeof(double) * e->N));
 
@@ -535,21 +573,18 @@ int rpf_device_fused(rpf_engine* e, const void* d_stream, size_t nbytes, int64_t
     nframes = std::min(nframes, repeats);
     if (nframes < 1) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_fused: no whole frame");
     if (repeats_done) *repeats_done = nframes;
-    const uint8_t* d_frames = static_cast<const uint8_t*>(d_stream);
-    const bool dma = e->use_dma && (reinterpret_cast<uintptr_t>(d_frames) % 16) == 0;
-    const int64_t wanted = (nframes + e->plan.fpw - 1) / e->plan.fpw;
-    const int grid = static_cast<int>(std::min<int64_t>(e->plan.grid, wanted));
-    HIP_TRY(e, rpf::launch_fft_accum(e->N, e->variant, e->has_window, dma, d_frames, nframes, e->d_twiddles,
-                                     e->d_window, e->d_partial, grid,
-                                     static_cast<hipStream_t>(hip_stream), &e->last));
-    return RPF_OK;
+    int nslots = 0;
+    int rc = launch_transform(e, static_cast<const uint8_t*>(d_stream), nframes,
+                              static_cast<hipStream_t>(hip_stream), &nslots);
+    if (rc == RPF_OK) e->last_slots = nslots;
+    return rc;
 }
 
 int rpf_device_reduce(rpf_engine* e, double* d_pwr_out, void* hip_stream)
 {
     if (!e || !d_pwr_out) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_reduce: NULL argument");
-    if (e->last.grid < 1) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_reduce: nothing to reduce");
-    HIP_TRY(e, rpf::launch_reduce(e->d_partial, e->last.grid, e->N, d_pwr_out,
+    if (e->last_slots < 1) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_reduce: nothing to reduce");
+    HIP_TRY(e, rpf::launch_reduce(e->d_partial, e->last_slots, e->N, d_pwr_out,
                                   /*accumulate=*/false, static_cast<hipStream_t>(hip_stream)));
     return RPF_OK;
 }

@@ -38,6 +38,17 @@ hipError_t launch_fft_accum(int N, int vid, bool window, bool use_dma, const uin
 hipError_t launch_reduce(const double* d_partial, int nslots, int N, double* d_out,
                          bool accumulate, hipStream_t stream);
 
+// ---- four-step path (rpf_fourstep.hip): N = 512 x 512 ------------------------
+constexpr int kFourStepBatch = 64;     // frames per K2a/K2b launch pair (128 MB of scratch)
+bool fourstep_supported(int N);
+size_t fourstep_scratch_bytes(int N);  // intermediate Y[batch][N2][N1] complex floats
+int fourstep_partial_slots(int N);     // partial spectra written by K2b (frame groups)
+hipError_t fourstep_prepare(int N, int device, LaunchInfo* li);
+// Frames [0, nframes) -> d_partial[slots][N] (overwritten); K3 then sums the slots.
+hipError_t launch_fourstep(int N, bool window, bool use_dma, const uint8_t* d_stream, long nframes,
+                           const cf* d_tw512, const cf* d_twN, const float* d_window, cf* d_scratch,
+                           double* d_partial, int max_grid, hipStream_t stream);
+
 // Master twiddle table W_N^k = exp(-2 pi i k / N), k in [0,N), evaluated in
 // long double and rounded once to float.
 void make_twiddles(int N, std::vector<cf>& out);

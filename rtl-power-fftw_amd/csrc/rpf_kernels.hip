@@ -30,29 +30,12 @@
 #include <cmath>
 #include <type_traits>
 
+#include "rpf_device_common.h"
 #include "rpf_kernels.h"
 
 namespace rpf {
 
 namespace {
-
-// Orders LDS traffic between the threads that exchange data: a workgroup
-// barrier when a frame spans several wavefronts, otherwise only a compiler
-// fence (one wavefront's DS instructions execute in order).
-template <bool BLOCK>
-__device__ __forceinline__ void exchange_sync()
-{
-    if constexpr (BLOCK) {
-        __syncthreads();
-    } else {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-}
-
-using gptr_t = const __attribute__((address_space(1))) void*;
-using lptr_t = __attribute__((address_space(3))) void*;
 
 // Stage the raw bytes this wavefront will unpack in the iteration whose slot-0
 // frame is `fb` (wave-local, a-major layout: fft_core.h raw_source).  P/8
@@ -78,34 +61,6 @@ __device__ __forceinline__ void stage_raw(const uint8_t* __restrict__ stream, lo
                 *reinterpret_cast<uint4*>(wave_raw + j) = *reinterpret_cast<const uint4*>(src);
             }
         }
-    }
-}
-
-template <class G, int J>
-__device__ __forceinline__ void load_twiddles(int t, const cf* __restrict__ twN,
-                                              cf (&tw)[G::NPASS - 1][G::P - 1])
-{
-    if constexpr (J < G::NPASS) {
-#pragma unroll
-        for (int r = 1; r < G::P; ++r) tw[J - 1][r - 1] = twN[twiddle_index<G, J>(t, r)];
-        load_twiddles<G, J + 1>(t, twN, tw);
-    }
-}
-
-// Passes J .. NPASS-1: [fetch] -> radix-P butterfly -> twiddle -> store -> sync.
-// Pass J > 1 reads and writes the same LDS slots per thread.  The exchange after
-// pass J stays inside groups of L_J threads, so it needs a workgroup barrier
-// only if L_J > 64.
-template <class G, int J>
-__device__ __forceinline__ void middle_passes(int t, cf* x,
-                                              const cf (&tw)[G::NPASS - 1][G::P - 1], cf* slab)
-{
-    if constexpr (J < G::NPASS) {
-        if constexpr (J > 1) phase_fetch<G, J>(t, x, slab);
-        phase_butterfly_twiddle<G>(x, tw[J - 1]);
-        phase_store<G, J>(t, x, slab);
-        exchange_sync<(G::Lcur(J) > 64)>();
-        middle_passes<G, J + 1>(t, x, tw, slab);
     }
 }
 

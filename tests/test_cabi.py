@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_supported_sizes():
     lib = rpf.load()
-    for n in (64, 128, 256, 512, 1024, 2048, 4096, 8192):
+    for n in (64, 128, 256, 512, 1024, 2048, 4096, 8192, 262144):
         assert lib.rpf_supported_n(n) == 1
     for n in (0, 2, 500, 513, 16384):
         assert lib.rpf_supported_n(n) == 0
