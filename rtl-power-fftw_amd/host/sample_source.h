@@ -1,0 +1,63 @@
+// sample_source.h -- where the IQ bytes come from.  Stands where `class Rtlsdr`
+// stands in the reference (/root/reference/src/device.h:28-54): tune, report the
+// sample rate, fill a Buffer.  There is no dongle next to an MI355X, so the two
+// implementations replay a byte stream (file / stdin) or synthesise one.
+#ifndef RPF_HOST_SAMPLE_SOURCE_H
+#define RPF_HOST_SAMPLE_SOURCE_H
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "datastore.h"
+
+namespace rpf_host {
+
+class SampleSource {
+public:
+    virtual ~SampleSource() {}
+    virtual void set_sample_rate(uint32_t rate) { rate_ = rate; }
+    virtual int sample_rate() const { return static_cast<int>(rate_); }
+    virtual void set_frequency(int64_t hz) { frequency_ = hz; }
+    virtual int64_t frequency() const { return frequency_; }
+    // Fill the whole buffer (buffer.size() bytes); false = dropped samples / end of data.
+    virtual bool read(Buffer& buffer) = 0;
+    // After a failed read the reference simply tries again (a dongle keeps
+    // streaming, acquisition.cxx:307-316); a finite replay has nothing more to give.
+    virtual bool retry_after_short_read() const { return true; }
+protected:
+    uint32_t rate_ = 2000000;
+    int64_t frequency_ = 0;
+};
+
+// Interleaved u8 I/Q from a file or stdin ("-"); a short read ends the data.
+class FileSource : public SampleSource {
+public:
+    explicit FileSource(const std::string& path);
+    ~FileSource() override;
+    bool read(Buffer& buffer) override;
+    bool retry_after_short_read() const override { return false; }
+private:
+    std::FILE* file_ = nullptr;
+    bool owns_ = false;
+};
+
+// The integer-only receiver model of rtl-power-fftw_amd/synth.py (noise_tones_iq):
+// identical bytes for the same seed, so the CLI can be checked against Python.
+// Tuning restarts the stream with a seed that depends only on the frequency,
+// seed_for(base, hz) = base + hz mod 9973, so every hop of a scan sees different
+// but reproducible data.
+class SyntheticSource : public SampleSource {
+public:
+    explicit SyntheticSource(uint64_t seed) : base_seed_(seed), seed_(seed) {}
+    void set_frequency(int64_t hz) override;
+    bool read(Buffer& buffer) override;
+    static uint64_t seed_for(uint64_t base, int64_t hz) { return base + static_cast<uint64_t>(hz % 9973); }
+    static void generate(uint64_t seed, uint64_t first_sample, uint64_t nsamples, uint8_t* out);
+private:
+    uint64_t base_seed_, seed_;
+    uint64_t position_ = 0;          // complex samples produced since the last tune
+};
+
+}  // namespace rpf_host
+#endif
