@@ -12,8 +12,9 @@ the 256 MiB Infinity Cache, so every step reads its bytes from HBM.
 
 N>1 (launched by torch.distributed.run, one rank per GPU): every rank owns an
 independent shard of the frames (weak scaling, per-GPU work fixed) and the
-per-bin accumulators are summed onto rank 0 with one RCCL reduce per step,
-issued asynchronously so it overlaps the next step's kernel.
+per-bin accumulators of 8 consecutive steps (the hops of one scan) are summed onto
+rank 0 with ONE asynchronous RCCL reduce of 8 x 4096 doubles that overlaps the
+following steps' kernels.
 
 Prints ONE JSON line on rank 0.
 """
@@ -98,6 +99,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--replay-buffers", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and run the per-step reduce even with one rank")
     ap.add_argument("--event-every", type=int, default=8,
                     help="bracket the fused kernel with HIP events on every k-th timed step")
     args = ap.parse_args()
@@ -109,13 +112,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if use_dist else 0)
     torch.cuda.set_device(dev)
 
     # ---- workload: this rank's shard of the frames (seeded per rank) ----------
@@ -128,24 +135,29 @@ def main():
     bufs = [d_base] + [torch.roll(d_base, shifts=2 * N_BINS * (37 * i)) for i in range(1, nb)]
 
     ds = rpf.Datastore(rpf.Params(N=N_BINS, repeats=REPEATS), device=dev.index or 0)
+    # Multi-GPU exchange: the spectra of HOPS consecutive steps (= the
+    # hops of one scan, config C5 has 8) meet in ONE reduce of HOPS*N doubles --
+    # fewer, larger collectives -- issued asynchronously on a ring of blocks so that
+    # it overlaps the following steps' kernels.
+    HOPS = 8
     nring = 4
-    d_pwr = [torch.zeros(N_BINS, dtype=torch.float64, device=dev) for _ in range(nring)]
+    d_pwr = [torch.zeros(HOPS, N_BINS, dtype=torch.float64, device=dev) for _ in range(nring)]
     s = torch.cuda.current_stream().cuda_stream
     pending = [None] * nring
 
     def step(i, ev=None):
-        k = i % nring
-        if pending[k] is not None:
-            pending[k].wait()
-            pending[k] = None
+        blk, hop = (i // HOPS) % nring, i % HOPS
+        if hop == 0 and pending[blk] is not None:
+            pending[blk].wait()
+            pending[blk] = None
         if ev is not None:
             ev[0].record()
         ds.device_fused(bufs[i % nb].data_ptr(), stream_bytes, REPEATS, s)
         if ev is not None:
             ev[1].record()
-        ds.device_reduce(d_pwr[k].data_ptr(), s)
-        if world > 1:
-            pending[k] = dist.reduce(d_pwr[k], dst=0, op=dist.ReduceOp.SUM, async_op=True)
+        ds.device_reduce(d_pwr[blk][hop].data_ptr(), s)
+        if use_dist and hop == HOPS - 1:
+            pending[blk] = dist.reduce(d_pwr[blk], dst=0, op=dist.ReduceOp.SUM, async_op=True)
 
     def drain():
         for k in range(nring):
@@ -153,9 +165,13 @@ def main():
                 pending[k].wait()
                 pending[k] = None
 
-    def fence():
+    def fence(last_step=None):
+        # a scan cut short by the step count still owes its (partial) reduce
+        if use_dist and last_step is not None and last_step % HOPS != HOPS - 1:
+            blk = (last_step // HOPS) % nring
+            dist.reduce(d_pwr[blk], dst=0, op=dist.ReduceOp.SUM)
         drain()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -167,7 +183,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    fence()
+    fence(args.warmup - 1 if args.warmup else None)
 
     events = []
     t0 = time.perf_counter()
@@ -177,10 +193,10 @@ def main():
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             events.append(ev)
         step(i, ev)
-    fence()
+    fence(args.steps - 1)
     elapsed = time.perf_counter() - t0
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -213,7 +229,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C2: N=4096 bins x 10000 repeats per step per GPU, rectangular window, "
                                    "u8 IQ resident in HBM (%d replay buffers of %d B)" % (nb, stream_bytes),
-                       "launch": info, "reduce": "RCCL reduce of 4096 f64 bins per step" if world > 1 else "none"},
+                       "launch": info, "reduce": "one async RCCL reduce of 8 x 4096 f64 bins per 8 steps" if use_dist else "none"},
             "roofline": roof,
         }
         if not args.no_cpu_baseline:
@@ -221,7 +237,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     ds.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
