@@ -31,6 +31,7 @@
 #include <thread>
 #include <vector>
 
+#include "bluestein_tables.h"
 #include "rpf_kernels.h"
 
 namespace {
@@ -82,6 +83,9 @@ struct rpf_engine {
     hipStream_t copy_stream = nullptr, compute_stream = nullptr;
     rpf::cf* d_twiddles = nullptr;
     bool fourstep = false;                // N handled by rpf_fourstep.hip
+    bool bluestein = false;               // N handled by the Bluestein kernel (chirp tables below)
+    rpf::cf* d_chirp = nullptr;           // g[n], N entries
+    rpf::cf* d_bhat = nullptr;            // frequency-domain chirp, M entries
     rpf::cf* d_tw_sub = nullptr;          // four-step: W_512 table of the sub-transforms
     rpf::cf* d_scratch = nullptr;         // four-step: intermediate Y
     float* d_window = nullptr;
@@ -129,9 +133,15 @@ int launch_transform(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, hi
         *nslots = rpf::fourstep_partial_slots(e->N);
         return RPF_OK;
     }
-    const bool dma = e->use_dma && (addr % 16) == 0;
     const int64_t wanted = (nframes + e->plan.fpw - 1) / e->plan.fpw;
     const int grid = static_cast<int>(std::min<int64_t>(e->plan.grid, wanted));
+    if (e->bluestein) {
+        HIP_TRY(e, rpf::launch_bluestein(e->N, d_frames, nframes, e->d_twiddles, e->d_chirp, e->d_bhat,
+                                         e->d_partial, grid, stream, &e->last));
+        *nslots = grid;
+        return RPF_OK;
+    }
+    const bool dma = e->use_dma && (addr % 16) == 0;
     HIP_TRY(e, rpf::launch_fft_accum(e->N, e->variant, e->has_window, dma, d_frames, nframes, e->d_twiddles,
                                      e->d_window, e->d_partial, grid, stream, &e->last));
     *nslots = grid;
@@ -257,6 +267,8 @@ void release_device(rpf_engine* e)
     if (e->d_twiddles) (void)hipFree(e->d_twiddles);
     if (e->d_tw_sub) (void)hipFree(e->d_tw_sub);
     if (e->d_scratch) (void)hipFree(e->d_scratch);
+    if (e->d_chirp) (void)hipFree(e->d_chirp);
+    if (e->d_bhat) (void)hipFree(e->d_bhat);
     if (e->d_window) (void)hipFree(e->d_window);
     if (e->d_partial) (void)hipFree(e->d_partial);
     if (e->d_pwr) (void)hipFree(e->d_pwr);
@@ -277,7 +289,10 @@ extern "C" {
 
 int rpf_abi_version(void) { return RPF_ABI_VERSION; }
 
-int rpf_supported_n(int N) { return (rpf::kernel_supported(N) || rpf::fourstep_supported(N)) ? 1 : 0; }
+int rpf_supported_n(int N)
+{
+    return (rpf::kernel_supported(N) || rpf::fourstep_supported(N) || rpf::bluestein_supported(N)) ? 1 : 0;
+}
 
 const char* rpf_last_global_error(void) { return g_last_error.c_str(); }
 
@@ -292,10 +307,11 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
                     "Number of bins must be a positive even number.");
     const int variant = static_cast<int>((cfg->flags >> 8) & 0xffu);
     const bool fourstep = rpf::fourstep_supported(cfg->N) && variant == 0;
-    if (!fourstep && !rpf::kernel_supported(cfg->N, variant))
+    const bool bluestein = rpf::bluestein_supported(cfg->N) && variant == 0;
+    if (!fourstep && !bluestein && !rpf::kernel_supported(cfg->N, variant))
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT,
                     "No gfx950 kernel for " + std::to_string(cfg->N) +
-                        " bins in this build (supported: powers of two 64..8192, and 262144).");
+                        " bins in this build (supported: every even N up to 2048, 4096, 8192 and 262144).");
     if (cfg->n_buffers < 1)
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT, "Argument to 'buffers' must be a positive number.");
     if (cfg->buffer_capacity < 2 || (cfg->buffer_capacity % 2) != 0)
@@ -321,6 +337,7 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
     e->use_dma = !(cfg->flags & RPF_FLAG_NO_LDS_DMA);
     e->variant = variant;
     e->fourstep = fourstep;
+    e->bluestein = bluestein;
     e->queue_histogram.assign(e->n_buffers + 1, 0);
     e->pwr.assign(e->N, 0.0);
 
@@ -344,15 +361,24 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
 
     // "plan": twiddle table on the device (where fftwf_plan_dft_1d stands, datastore.cxx:32)
     std::vector<rpf::cf> tw;
-    rpf::make_twiddles(e->N, tw);
-    CREATE_TRY(hipMalloc(&e->d_twiddles, sizeof(rpf::cf) * e->N));
-    CREATE_TRY(hipMemcpy(e->d_twiddles, tw.data(), sizeof(rpf::cf) * e->N, hipMemcpyHostToDevice));
+    rpf::make_twiddles(e->bluestein ? rpf::bluestein_length(e->N) : e->N, tw);
+    CREATE_TRY(hipMalloc(&e->d_twiddles, sizeof(rpf::cf) * tw.size()));
+    CREATE_TRY(hipMemcpy(e->d_twiddles, tw.data(), sizeof(rpf::cf) * tw.size(), hipMemcpyHostToDevice));
     if (e->has_window) {
         CREATE_TRY(hipMalloc(&e->d_window, sizeof(float) * e->N));
         CREATE_TRY(hipMemcpy(e->d_window, cfg->window, sizeof(float) * e->N, hipMemcpyHostToDevice));
     }
     size_t partial_slots = 0;
-    if (e->fourstep) {
+    if (e->bluestein) {
+        std::vector<float> g, bhat;
+        rpf::make_bluestein_tables(e->N, cfg->window, g, bhat);
+        CREATE_TRY(hipMalloc(&e->d_chirp, sizeof(float) * g.size()));
+        CREATE_TRY(hipMemcpy(e->d_chirp, g.data(), sizeof(float) * g.size(), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc(&e->d_bhat, sizeof(float) * bhat.size()));
+        CREATE_TRY(hipMemcpy(e->d_bhat, bhat.data(), sizeof(float) * bhat.size(), hipMemcpyHostToDevice));
+        CREATE_TRY(rpf::plan_bluestein(e->N, e->device, &e->plan));
+        partial_slots = e->plan.grid;
+    } else if (e->fourstep) {
         CREATE_TRY(rpf::fourstep_prepare(e->N, e->device, &e->plan));
         std::vector<rpf::cf> tws;
         rpf::make_twiddles(512, tws);

@@ -38,6 +38,14 @@ hipError_t launch_fft_accum(int N, int vid, bool window, bool use_dma, const uin
 hipError_t launch_reduce(const double* d_partial, int nslots, int N, double* d_out,
                          bool accumulate, hipStream_t stream);
 
+// ---- Bluestein path (KB in rpf_kernels.hip): any other even N <= 2048 ----------
+bool bluestein_supported(int N);
+hipError_t plan_bluestein(int N, int device, LaunchInfo* li);
+// d_twM: master twiddles of length M = bluestein_length(N); d_g / d_bhat: bluestein_tables.h
+hipError_t launch_bluestein(int N, const uint8_t* d_stream, long nframes, const cf* d_twM,
+                            const cf* d_g, const cf* d_bhat, double* d_partial, int grid,
+                            hipStream_t stream, LaunchInfo* li);
+
 // ---- four-step path (rpf_fourstep.hip): N = 512 x 512 ------------------------
 constexpr int kFourStepBatch = 64;     // frames per K2a/K2b launch pair (128 MB of scratch)
 bool fourstep_supported(int N);

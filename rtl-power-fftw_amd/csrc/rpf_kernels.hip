@@ -30,6 +30,9 @@
 #include <cmath>
 #include <type_traits>
 
+#include <algorithm>
+
+#include "bluestein_tables.h"
 #include "rpf_device_common.h"
 #include "rpf_kernels.h"
 
@@ -154,6 +157,90 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
     }
 }
 
+// KB  bluestein_kernel -- any even N <= 2048 that is not one of K1's powers of two
+// (bluestein_tables.h).  G = Geom<M, P> with M = 2^ceil(log2(2N-1)); per frame:
+//   a[n] = (v[n] - 127) * g[n] for n < N, zero-padded to M      (g carries (-1)^n, window, chirp)
+//   A = FFT_M(a);  z = conj(A * bhat);  c = FFT_M(z)            (= conj of the circular convolution)
+//   pwr[k] += |c[k]|^2 for k < N                                (|X[k]| = |c[k]|)
+// The two transforms reuse K1's passes; between them the spectrum goes through
+// the slab once more (digit-reversed -> natural order).  Samples are read
+// straight from HBM as coalesced u16 loads (frames are only 4-byte aligned).
+template <class G, int WG, int OCC>
+__global__ __launch_bounds__(WG, OCC) void bluestein_kernel(const uint8_t* __restrict__ stream,
+                                                            long nframes, int N,
+                                                            const cf* __restrict__ twM,
+                                                            const cf* __restrict__ g,
+                                                            const cf* __restrict__ bhat,
+                                                            double* __restrict__ partial)
+{
+    constexpr int P = G::P, T = G::T, M = G::N, NPASS = G::NPASS;
+    constexpr int FPW = WG / T;
+    constexpr bool BLOCK_SYNC = (T > 64);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int fs = tid / T, t = tid % T;
+    cf* const slab = reinterpret_cast<cf*>(smem) + fs * G::LDS_CPX;
+
+    cf tw[NPASS - 1][P - 1];
+    load_twiddles<G, 1>(t, twM, tw);
+    double acc[P];
+#pragma unroll
+    for (int a = 0; a < P; ++a) acc[a] = 0.0;
+
+    const long stride = static_cast<long>(gridDim.x) * FPW;
+    for (long fb = static_cast<long>(blockIdx.x) * FPW; fb < nframes; fb += stride) {
+        const bool active = (fb + fs) < nframes;
+        const uint8_t* const frame = stream + (fb + fs) * 2 * static_cast<long>(N);
+        cf x[P];
+#pragma unroll
+        for (int a = 0; a < P; ++a) {
+            const int n = t + T * a;
+            x[a] = cf{0.0f, 0.0f};
+            if (active && n < N) {
+                const uint32_t iq = *reinterpret_cast<const uint16_t*>(frame + 2 * n);
+                const cf v = cf{byte_plus_2p23(iq & 0xffu), byte_plus_2p23(iq >> 8)} - (kTwo23 + 127.0f);
+                x[a] = cmul(v, g[n]);
+            }
+        }
+        exchange_sync<BLOCK_SYNC>();             // previous frame's slab reads are done
+        middle_passes<G, 1>(t, x, tw, slab);
+        phase_fetch<G, NPASS>(t, x, slab);
+        phase_last<G>(x);
+        exchange_sync<BLOCK_SYNC>();             // ... before the slab is rewritten in another order
+#pragma unroll
+        for (int a = 0; a < P; ++a) {
+            const int j = bin_of<G>(t, a);
+            cf z = cmul(x[a], bhat[j]);
+            z.y = -z.y;
+            slab[G::slot(j)] = z;
+        }
+        exchange_sync<BLOCK_SYNC>();
+        phase_fetch<G, 1>(t, x, slab);           // natural order: lane t gets elements t + T a
+        middle_passes<G, 1>(t, x, tw, slab);     // its pass-1 store rewrites exactly those slots
+        phase_fetch<G, NPASS>(t, x, slab);
+        phase_last<G>(x);
+        if (active) phase_accumulate(x, acc, P);
+    }
+
+    // partial spectrum: only the first N of the M convolution outputs are bins
+    exchange_sync<true>();
+    double* const stage = reinterpret_cast<double*>(smem);
+    constexpr int SM = M + M / 16;
+#pragma unroll
+    for (int a = 0; a < P; ++a) {
+        const int bin = bin_of<G>(t, a);
+        stage[fs * SM + bin + (bin >> 4)] = acc[a];
+    }
+    exchange_sync<true>();
+    double* out = partial + static_cast<size_t>(blockIdx.x) * N;
+    for (int bin = tid; bin < N; bin += WG) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < FPW; ++k) v += stage[k * SM + bin + (bin >> 4)];
+        out[bin] = v;
+    }
+}
+
 // K3.  out[bin] = (accumulate ? out[bin] : 0) + sum over workgroup partials, in
 // a fixed order (bit-reproducible for a given grid): thread (g, b) sums the
 // partials g, g+16, g+32, ... of bin b with 8 independent loads in flight, then
@@ -233,6 +320,34 @@ const Variant* find_variant(int N, int vid)
     return nullptr;
 }
 
+using BluesteinFn = void (*)(const uint8_t*, long, int, const cf*, const cf*, const cf*, double*);
+struct BluesteinVariant {
+    int M, WG, fpw, lds_bytes;
+    BluesteinFn fn;
+};
+template <int M, int P, int OCC>
+BluesteinVariant make_bluestein()
+{
+    using G = Geom<M, P>;
+    constexpr int WG = G::T >= 256 ? G::T : 256;
+    constexpr int FPW = WG / G::T;
+    return BluesteinVariant{M, WG, FPW, FPW * G::LDS_CPX * (int)sizeof(cf), bluestein_kernel<G, WG, OCC>};
+}
+const BluesteinVariant kBluestein[] = {
+    make_bluestein<64, 8, 4>(),    make_bluestein<128, 8, 4>(),   make_bluestein<256, 8, 4>(),
+    // P = 8 throughout (two inlined transforms per frame: 16 points per lane
+    // spills even at 256 registers); M = 8192 would need 1024-thread workgroups
+    // capped at 128 registers, so Bluestein stops at N = 2048 (M = 4096).
+    make_bluestein<512, 8, 4>(),   make_bluestein<1024, 8, 2>(),  make_bluestein<2048, 8, 2>(),
+    make_bluestein<4096, 8, 2>(),
+};
+const BluesteinVariant* find_bluestein(int M)
+{
+    for (const BluesteinVariant& v : kBluestein)
+        if (v.M == M) return &v;
+    return nullptr;
+}
+
 }  // namespace
 
 bool kernel_supported(int N, int vid) { return find_variant(N, vid) != nullptr; }
@@ -269,6 +384,50 @@ hipError_t launch_fft_accum(int N, int vid, bool window, bool use_dma, const uin
     KernelFn fn = v->fn[window ? 1 : 0][use_dma ? 1 : 0];
     hipLaunchKernelGGL(fn, dim3(grid), dim3(v->WG), v->lds_bytes, stream, d_stream, nframes,
                        d_twiddles, d_window, d_partial);
+    if (li) {
+        li->grid = grid;
+        li->block = v->WG;
+        li->fpw = v->fpw;
+        li->lds_bytes = v->lds_bytes;
+    }
+    return hipGetLastError();
+}
+
+bool bluestein_supported(int N)
+{
+    return N >= 2 && N % 2 == 0 && N <= 2048 && !kernel_supported(N, 0) &&
+           find_bluestein(bluestein_length(N)) != nullptr;
+}
+
+hipError_t plan_bluestein(int N, int device, LaunchInfo* li)
+{
+    const BluesteinVariant* v = bluestein_supported(N) ? find_bluestein(bluestein_length(N)) : nullptr;
+    if (!v) return hipErrorInvalidValue;
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(v->fn),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, v->lds_bytes);
+    if (err != hipSuccess) return err;
+    int per_cu = 0;
+    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(v->fn),
+                                                       v->WG, v->lds_bytes);
+    if (err != hipSuccess) return err;
+    hipDeviceProp_t prop;
+    err = hipGetDeviceProperties(&prop, device);
+    if (err != hipSuccess) return err;
+    li->grid = std::max(per_cu, 1) * prop.multiProcessorCount;
+    li->block = v->WG;
+    li->fpw = v->fpw;
+    li->lds_bytes = v->lds_bytes;
+    return hipSuccess;
+}
+
+hipError_t launch_bluestein(int N, const uint8_t* d_stream, long nframes, const cf* d_twM,
+                            const cf* d_g, const cf* d_bhat, double* d_partial, int grid,
+                            hipStream_t stream, LaunchInfo* li)
+{
+    const BluesteinVariant* v = bluestein_supported(N) ? find_bluestein(bluestein_length(N)) : nullptr;
+    if (!v || grid < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(v->fn, dim3(grid), dim3(v->WG), v->lds_bytes, stream, d_stream, nframes, N, d_twM,
+                       d_g, d_bhat, d_partial);
     if (li) {
         li->grid = grid;
         li->block = v->WG;

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <vector>
 
+#include "../../rtl-power-fftw_amd/csrc/bluestein_tables.h"
 #include "../../rtl-power-fftw_amd/csrc/fft_core.h"
 
 namespace {
@@ -98,6 +99,65 @@ int run(const float* window, const uint8_t* stream, long nframes, double* pwr)
     return 0;
 }
 
+// Bluestein kernel (bluestein_kernel in rpf_kernels.hip), same phase order.
+template <int M, int P>
+int run_bluestein(int N, const float* window, const uint8_t* stream, long nframes, double* pwr)
+{
+    using G = rpf::Geom<M, P>;
+    constexpr int T = G::T;
+    std::vector<cf> twM(M);
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (int k = 0; k < M; ++k) {
+        long double a = two_pi * k / M;
+        twM[k] = {(float)cosl(a), (float)(-sinl(a))};
+    }
+    std::vector<float> g, bhat;
+    rpf::make_bluestein_tables(N, window, g, bhat);
+    std::vector<std::vector<cf>> tws(T, std::vector<cf>((G::NPASS - 1) * (P - 1)));
+    for (int t = 0; t < T; ++t)
+        load_tw<G, 1>(t, twM, reinterpret_cast<cf(*)[P - 1]>(tws[t].data()));
+    std::vector<std::vector<cf>> regs(T, std::vector<cf>(P));
+    std::vector<std::vector<double>> acc(T, std::vector<double>(P, 0.0));
+    std::vector<cf> slab(G::LDS_CPX);
+    for (long f = 0; f < nframes; ++f) {
+        const uint8_t* frame = stream + (size_t)f * 2 * N;
+        for (int t = 0; t < T; ++t)
+            for (int a = 0; a < P; ++a) {
+                const int n = t + T * a;
+                regs[t][a] = cf{0.0f, 0.0f};
+                if (n < N) {
+                    const cf v = cf{(float)frame[2 * n] - 127.0f, (float)frame[2 * n + 1] - 127.0f};
+                    regs[t][a] = rpf::cmul(v, cf{g[2 * n], g[2 * n + 1]});
+                }
+            }
+        middle<G, 1>(regs, slab, tws);
+        for (int t = 0; t < T; ++t) {
+            rpf::phase_fetch<G, G::NPASS>(t, regs[t].data(), slab.data());
+            rpf::phase_last<G>(regs[t].data());
+        }
+        for (int t = 0; t < T; ++t)
+            for (int a = 0; a < P; ++a) {
+                const int j = rpf::bin_of<G>(t, a);
+                cf z = rpf::cmul(regs[t][a], cf{bhat[2 * j], bhat[2 * j + 1]});
+                z.y = -z.y;
+                slab[G::slot(j)] = z;
+            }
+        for (int t = 0; t < T; ++t) rpf::phase_fetch<G, 1>(t, regs[t].data(), slab.data());
+        middle<G, 1>(regs, slab, tws);
+        for (int t = 0; t < T; ++t) {
+            rpf::phase_fetch<G, G::NPASS>(t, regs[t].data(), slab.data());
+            rpf::phase_last<G>(regs[t].data());
+            rpf::phase_accumulate(regs[t].data(), acc[t].data(), P);
+        }
+    }
+    for (int t = 0; t < T; ++t)
+        for (int a = 0; a < P; ++a) {
+            const int bin = rpf::bin_of<G>(t, a);
+            if (bin < N) pwr[bin] = acc[t][a];
+        }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int rpf_emul_accumulate(int N, int P, const float* window, const uint8_t* stream,
@@ -107,5 +167,19 @@ extern "C" int rpf_emul_accumulate(int N, int P, const float* window, const uint
     CASE(64, 8); CASE(128, 8); CASE(256, 8); CASE(512, 8); CASE(1024, 8); CASE(4096, 8);
     CASE(1024, 16); CASE(2048, 16); CASE(4096, 16); CASE(8192, 16); CASE(256, 16); CASE(512, 16);
 #undef CASE
+    return -1;
+}
+
+extern "C" int rpf_emul_bluestein(int N, const float* window, const uint8_t* stream, long nframes, double* pwr)
+{
+    switch (rpf::bluestein_length(N)) {
+        case 64: return run_bluestein<64, 8>(N, window, stream, nframes, pwr);
+        case 128: return run_bluestein<128, 8>(N, window, stream, nframes, pwr);
+        case 256: return run_bluestein<256, 8>(N, window, stream, nframes, pwr);
+        case 512: return run_bluestein<512, 8>(N, window, stream, nframes, pwr);
+        case 1024: return run_bluestein<1024, 8>(N, window, stream, nframes, pwr);
+        case 2048: return run_bluestein<2048, 8>(N, window, stream, nframes, pwr);
+        case 4096: return run_bluestein<4096, 8>(N, window, stream, nframes, pwr);
+    }
     return -1;
 }

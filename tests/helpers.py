@@ -66,6 +66,7 @@ def emul_lib():
     if _emul is None:
         lib = ctypes.CDLL(os.path.join(ROOT, "tests", "emul", "librpf_emul.so"))
         lib.rpf_emul_accumulate.argtypes = [ctypes.c_int, ctypes.c_int, fp, u8p, ctypes.c_long, dp]
+        lib.rpf_emul_bluestein.argtypes = [ctypes.c_int, fp, u8p, ctypes.c_long, dp]
         _emul = lib
     return _emul
 
@@ -124,6 +125,18 @@ def emul_accumulate(N, P, stream, nframes, window=None):
         w = window.ctypes.data_as(fp)
     rc = emul_lib().rpf_emul_accumulate(N, P, w, stream.ctypes.data_as(u8p), nframes, pwr.ctypes.data_as(dp))
     assert rc == 0, "no emulator instantiation for N=%d P=%d" % (N, P)
+    return pwr
+
+
+def emul_bluestein(N, stream, nframes, window=None):
+    stream = np.ascontiguousarray(stream, dtype=np.uint8)
+    pwr = np.zeros(N)
+    w = None
+    if window is not None:
+        window = np.ascontiguousarray(window, dtype=np.float32)
+        w = window.ctypes.data_as(fp)
+    rc = emul_lib().rpf_emul_bluestein(N, w, stream.ctypes.data_as(u8p), nframes, pwr.ctypes.data_as(dp))
+    assert rc == 0, "no Bluestein emulation for N=%d" % N
     return pwr
 
 

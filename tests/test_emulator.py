@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import rtl_power_fftw_amd as rpf
-from helpers import emul_accumulate, max_err_over_mean, max_rel, oracle_accumulate, truth_f64
+from helpers import emul_accumulate, emul_bluestein, max_err_over_mean, max_rel, oracle_accumulate, truth_f64
 
 CASES = [(64, 8), (128, 8), (256, 8), (512, 8), (1024, 8), (4096, 8), (256, 16), (512, 16),
          (1024, 16), (2048, 16), (4096, 16), (8192, 16)]
@@ -36,3 +36,17 @@ def test_emulated_kernel_bin_placement(N, P):
     got = emul_accumulate(N, P, frame, 1)
     assert int(np.argmax(got)) == (k0 + N // 2) % N
     assert np.sort(got)[-2] < 1e-3 * got.max()
+
+
+@pytest.mark.parametrize("N", [2, 6, 30, 32, 100, 500, 1000, 1536, 2046])
+@pytest.mark.parametrize("windowed", [False, True])
+def test_emulated_bluestein_kernel_matches_oracle(N, windowed):
+    """Sizes that are not powers of two (the man page's -b 500 among them) go
+    through Bluestein's chirp convolution on a power-of-two transform."""
+    R = 32
+    stream = rpf.synth.uniform_iq(N, N * R)
+    w = rpf.synth.hann_window(N) + np.float32(0.25) if windowed else None
+    got = emul_bluestein(N, stream, R, w)
+    assert max_rel(got, truth_f64(N, stream, R, w)) < 1e-6
+    o32, _ = oracle_accumulate(N, stream, R, w, 32)
+    assert max_rel(got, o32) < 1e-6

@@ -90,6 +90,24 @@ def test_tuning_variants_agree(N, variant, torch_dev):
     assert max_rel(pb, truth_f64(N, stream, R)) < VS_TRUTH
 
 
+@pytest.mark.parametrize("N", [2, 6, 30, 32, 100, 500, 1000, 1536, 2046])
+@pytest.mark.parametrize("windowed", [False, True])
+def test_non_power_of_two_sizes_match_oracle(N, windowed, torch_dev):
+    """Any even N up to 2048 (the reference takes any even N because FFTW does;
+    the man page's example is -b 500): Bluestein kernel, device and queue paths."""
+    R = 61
+    stream = rpf.synth.uniform_iq(900 + N, N * R + 7 * N // 2)
+    w = rpf.synth.hann_window(N) + np.float32(0.25) if windowed else None
+    with rpf.Datastore(rpf.Params(N=N, window=windowed, repeats=R, buf_length=16384), w) as ds:
+        got, n = run_device(ds, stream, R, torch_dev)
+        host, done = ds.accumulate(stream, R)          # 16 KB buffers: frames straddle them
+    assert n == done == R
+    o32, _ = oracle_accumulate(N, stream, R, w, 32)
+    assert max_rel(got, o32) < PARITY
+    assert max_rel(got, truth_f64(N, stream, R, w)) < PARITY
+    assert max_rel(host, got) < 1e-13
+
+
 def test_four_step_size_matches_oracle(torch_dev):
     """Config C4's size (N = 262144 = 512 x 512, rpf_fourstep.hip) on noise-only
     input, against the float32 oracle and float64 truth, windowed and not."""
