@@ -73,13 +73,14 @@ RPF_HD cf mul_pi(cf a) { return pk_add_mod<1, 0, 1, 0, 0, 0, 0, 0>(a, cf{0.0f, 0
 RPF_HD cf cmul(cf a, cf w)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    cf t, d;
-    // t = (a.x w.x, a.y w.x)
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
-    // d = (a.y (-w.y) + t.x, a.x w.y + t.y)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
-        : "=v"(d)
-        : "v"(a), "v"(w), "v"(t));
+    // One asm statement for both instructions: hipcc pads every asm boundary whose
+    // result feeds the next instruction with an s_nop, and an s_nop costs the wave
+    // an issue slot.  d = (a.x w.x, a.y w.x); then d = (a.y (-w.y) + d.x, a.x w.y + d.y).
+    cf d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+        : "=&v"(d)
+        : "v"(a), "v"(w));
     return d;
 #else
     return cf{__builtin_fmaf(-a.y, w.y, a.x * w.x), __builtin_fmaf(a.x, w.y, a.y * w.x)};
@@ -264,6 +265,19 @@ RPF_HD float byte_plus_2p23(uint32_t b)
 {
     return __builtin_bit_cast(float, 0x4B000000u | b);
 }
+// (2^23 + I, 2^23 + Q) of one interleaved sample iq = I | Q << 8: on the device
+// one v_perm_b32 per component picks the byte and the 0x4B exponent byte at once.
+RPF_HD cf iq_plus_2p23(uint32_t iq)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    // perm(S0, S1, sel): result byte i = byte sel[i] of {S0 (4..7), S1 (0..3)}; 0x0c = zero
+    const uint32_t bi = __builtin_amdgcn_perm(0x4B000000u, iq, 0x070c0c00u);
+    const uint32_t bq = __builtin_amdgcn_perm(0x4B000000u, iq, 0x070c0c01u);
+    return cf{__builtin_bit_cast(float, bi), __builtin_bit_cast(float, bq)};
+#else
+    return cf{byte_plus_2p23(iq & 0xffu), byte_plus_2p23((iq >> 8) & 0xffu)};
+#endif
+}
 constexpr float kTwo23 = 8388608.0f;
 
 // Raw-byte staging is wavefront-local: a wave stages exactly the samples its own
@@ -294,7 +308,7 @@ RPF_HD void phase_unpack(const uint8_t* lane_raw, float sgn, const float* wsgn, 
 #pragma unroll
     for (int a = 0; a < G::P; ++a) {
         const uint32_t iq = *reinterpret_cast<const uint16_t*>(lane_raw + kRawChunk * a);
-        const cf f = cf{byte_plus_2p23(iq & 0xffu), byte_plus_2p23(iq >> 8)};
+        const cf f = iq_plus_2p23(iq);
         if constexpr (WINDOW) {
             // (v - 127) is exact, * (+-w) rounds once: same value as the reference
             x[a] = (f - (kTwo23 + 127.0f)) * wsgn[a];

@@ -9,14 +9,57 @@
 namespace rpf {
 namespace {
 
-// Orders LDS traffic between the threads that exchange data: a workgroup
-// barrier when a frame spans several wavefronts, otherwise only a compiler
-// fence (one wavefront's DS instructions execute in order).
+// Optional per-phase cycle stamps (build with -DRPF_PHASE_TIMING; never in the
+// shipped library): each wave adds s_memtime deltas into g_phase_cycles so that
+// tools/gpu_phases.py can print where a frame's cycles go.
+#ifdef RPF_PHASE_TIMING
+constexpr int kPhaseSlots = 16;
+__device__ unsigned long long g_phase_cycles[kPhaseSlots];
+__device__ unsigned long long g_phase_waves;
+struct PhaseClock {
+    unsigned long long last;
+    unsigned long long sum[kPhaseSlots];
+    __device__ __forceinline__ void start()
+    {
+        for (int i = 0; i < kPhaseSlots; ++i) sum[i] = 0;
+        last = __builtin_readcyclecounter();
+    }
+    __device__ __forceinline__ void stamp(int i)
+    {
+        const unsigned long long now = __builtin_readcyclecounter();
+        sum[i] += now - last;
+        last = now;
+    }
+    __device__ __forceinline__ void publish(int lane)
+    {
+        if (lane == 0) {
+            for (int i = 0; i < kPhaseSlots; ++i) atomicAdd(&g_phase_cycles[i], sum[i]);
+            atomicAdd(&g_phase_waves, 1ull);
+        }
+    }
+};
+#define RPF_STAMP(clk, i) (clk).stamp(i)
+#else
+struct PhaseClock {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void publish(int) {}
+};
+#define RPF_STAMP(clk, i) ((void)0)
+#endif
+
+// Orders LDS traffic between the threads that exchange data.  A frame that spans
+// several wavefronts needs s_barrier; it is issued raw, after waiting for this
+// wave's LDS operations only (lgkmcnt): __syncthreads() would also drain vmcnt
+// and with it the LDS-DMA prefetch of the coming frames, exposing the full HBM
+// latency once per frame (measured: 3/4 of the kernel time).  LDS-DMA data is
+// ordered by the issuing wave's own counted vmcnt wait, and a wave only ever
+// reads bytes it staged itself.  Exchanges inside one wavefront need only a
+// compiler fence (one wavefront's DS instructions execute in order).
 template <bool BLOCK>
 __device__ __forceinline__ void exchange_sync()
 {
     if constexpr (BLOCK) {
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -44,15 +87,30 @@ __device__ __forceinline__ void load_twiddles(int t, const cf* __restrict__ twN,
 // only if L_J > 64.
 template <class G, int J>
 __device__ __forceinline__ void middle_passes(int t, cf* x,
-                                              const cf (&tw)[G::NPASS - 1][G::P - 1], cf* slab)
+                                              const cf (&tw)[G::NPASS - 1][G::P - 1], cf* slab,
+                                              PhaseClock& clk)
 {
     if constexpr (J < G::NPASS) {
-        if constexpr (J > 1) phase_fetch<G, J>(t, x, slab);
+        if constexpr (J > 1) {
+            phase_fetch<G, J>(t, x, slab);
+            asm volatile("" : "+v"(x[0]));   // (timing builds: keep the fetch before the stamp)
+            RPF_STAMP(clk, 4 * J);
+        }
         phase_butterfly_twiddle<G>(x, tw[J - 1]);
+        RPF_STAMP(clk, 4 * J + 1);
         phase_store<G, J>(t, x, slab);
+        RPF_STAMP(clk, 4 * J + 2);
         exchange_sync<(G::Lcur(J) > 64)>();
-        middle_passes<G, J + 1>(t, x, tw, slab);
+        RPF_STAMP(clk, 4 * J + 3);
+        middle_passes<G, J + 1>(t, x, tw, slab, clk);
     }
+}
+template <class G, int J>
+__device__ __forceinline__ void middle_passes(int t, cf* x,
+                                              const cf (&tw)[G::NPASS - 1][G::P - 1], cf* slab)
+{
+    PhaseClock none;
+    middle_passes<G, J>(t, x, tw, slab, none);
 }
 
 }  // namespace

@@ -157,7 +157,8 @@ int launch_frames(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, doubl
     int rc = launch_transform(e, d_frames, nframes, stream, &nslots);
     if (rc != RPF_OK) return rc;
     e->last_slots = nslots;
-    HIP_TRY(e, rpf::launch_reduce(e->d_partial, nslots, e->N, d_out, accumulate, stream));
+    HIP_TRY(e, rpf::launch_reduce(e->d_partial, nslots, e->N, d_out, accumulate, stream,
+                                  e->plan.partial_f32));
     return RPF_OK;
 }
 
@@ -611,7 +612,8 @@ int rpf_device_reduce(rpf_engine* e, double* d_pwr_out, void* hip_stream)
     if (!e || !d_pwr_out) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_reduce: NULL argument");
     if (e->last_slots < 1) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_reduce: nothing to reduce");
     HIP_TRY(e, rpf::launch_reduce(e->d_partial, e->last_slots, e->N, d_pwr_out,
-                                  /*accumulate=*/false, static_cast<hipStream_t>(hip_stream)));
+                                  /*accumulate=*/false, static_cast<hipStream_t>(hip_stream),
+                                  e->plan.partial_f32));
     return RPF_OK;
 }
 

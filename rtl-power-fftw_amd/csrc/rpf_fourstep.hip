@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_cols_kernel(const uint8_t* __
                 const int n1 = t + 64 * a;
                 const uint32_t iq =
                     *reinterpret_cast<const uint16_t*>(raw + 4 * (n1 * kRowDwords + (cl >> 1)) + 2 * (cl & 1));
-                const cf v = cf{byte_plus_2p23(iq & 0xffu), byte_plus_2p23(iq >> 8)};
+                const cf v = iq_plus_2p23(iq);
                 if constexpr (WINDOW) {
                     const float w = window[static_cast<size_t>(kN2) * n1 + c] * sgn;
                     x[a] = (v - (kTwo23 + 127.0f)) * w;

@@ -16,6 +16,7 @@ struct LaunchInfo {
     int block = 0;       // threads per workgroup
     int fpw = 0;         // frames processed concurrently by one workgroup
     int lds_bytes = 0;   // dynamic LDS per workgroup
+    bool partial_f32 = false;   // partial spectra are float32 (tuning variants), else f64
 };
 
 // Is there a fused kernel for N bins (tuning variant vid, 0 = default)?
@@ -36,7 +37,7 @@ hipError_t launch_fft_accum(int N, int vid, bool window, bool use_dma, const uin
 // d_out[bin] = (accumulate ? d_out[bin] : 0) + sum_{s < nslots} d_partial[s*N + bin],
 // summed in slot order (deterministic).
 hipError_t launch_reduce(const double* d_partial, int nslots, int N, double* d_out,
-                         bool accumulate, hipStream_t stream);
+                         bool accumulate, hipStream_t stream, bool partial_f32 = false);
 
 // ---- Bluestein path (KB in rpf_kernels.hip): any other even N <= 2048 ----------
 bool bluestein_supported(int N);

@@ -43,6 +43,9 @@ namespace {
 // Stage the raw bytes this wavefront will unpack in the iteration whose slot-0
 // frame is `fb` (wave-local, a-major layout: fft_core.h raw_source).  P/8
 // instructions per wave, each moving 64 lanes x 16 B = eight 128-byte rows.
+// Frames past the end are clamped to the last frame (never accumulated) so that
+// every iteration issues the same number of DMA instructions and the counted
+// s_waitcnt vmcnt(N) at the top of the frame loop stays exact.
 template <class G, bool DMA>
 __device__ __forceinline__ void stage_raw(const uint8_t* __restrict__ stream, long fb,
                                           long nframes, uint8_t* wave_raw, int wave, int lane)
@@ -54,15 +57,14 @@ __device__ __forceinline__ void stage_raw(const uint8_t* __restrict__ stream, lo
         const int j = i * 1024 + lane * 16;
         int slot, off;
         raw_source<G>(wave, j, &slot, &off);
-        const long f = fb + slot;
-        if (f < nframes) {
-            const uint8_t* src = stream + f * FRAME_BYTES + off;
-            if constexpr (DMA) {
-                // LDS address = wave-uniform base + 16 * lane (added by the hardware)
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wave_raw + i * 1024), 16, 0, 0);
-            } else {
-                *reinterpret_cast<uint4*>(wave_raw + j) = *reinterpret_cast<const uint4*>(src);
-            }
+        long f = fb + slot;
+        f = f < nframes ? f : nframes - 1;
+        const uint8_t* src = stream + f * FRAME_BYTES + off;
+        if constexpr (DMA) {
+            // LDS address = wave-uniform base + 16 * lane (added by the hardware)
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wave_raw + i * 1024), 16, 0, 0);
+        } else {
+            *reinterpret_cast<uint4*>(wave_raw + j) = *reinterpret_cast<const uint4*>(src);
         }
     }
 }
@@ -72,7 +74,19 @@ __device__ __forceinline__ void stage_raw(const uint8_t* __restrict__ stream, lo
 // finished reading frame f's slab; with two, the single barrier after the pass-1
 // store orders both hazards and a frame costs one s_barrier instead of two, at
 // the price of LDS (fewer resident workgroups).
-template <class G, int WG, int OCC, bool WINDOW, bool DMA, bool DBUF>
+//
+// RAWD: depth of the raw-byte ring = frames staged ahead by LDS-DMA.  The HBM
+// latency seen by a DMA under load is several frame times (measured ~3 us vs
+// ~1 us of butterflies per frame), so one frame ahead leaves the workgroup idle
+// most of the time; RAWD frames ahead keep RAWD x 2N bytes per workgroup in flight.
+// ACCB > 0 (tuning variants): |X|^2 is first summed over ACCB frames in packed
+// float32 (one v_pk_fma_f32 per bin instead of four half-rate f64 instructions)
+// and only then folded into the f64 accumulators -- adds <= ~1e-7 relative error
+// per batch, averaged down over the batches.  PF32: partial spectra leave as
+// float32 (half the flush and K3 traffic; each partial is a sum over ~13 frames
+// and there are hundreds of them, so the rounding averages out to ~1e-9).
+template <class G, int WG, int OCC, bool WINDOW, bool DMA, bool DBUF, int ACCB = 0, bool PF32 = false,
+          int RAWD = 2>
 __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __restrict__ stream,
                                                             long nframes,
                                                             const cf* __restrict__ twN,
@@ -87,13 +101,14 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* const slab_base = reinterpret_cast<cf*>(smem);                        // [NSLAB][FPW][LDS_CPX]
-    uint8_t* const raw_base = smem + NSLAB * FPW * G::LDS_CPX * sizeof(cf);  // [WG/64][128 P]
+    uint8_t* const raw_base = smem + NSLAB * FPW * G::LDS_CPX * sizeof(cf);  // [WG/64][RAWD][128 P]
 
     const int tid = threadIdx.x;
     const int fs = tid / T, t = tid % T;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    uint8_t* const wave_raw = raw_base + wave * (kRawChunk * P);
-    const uint8_t* const lane_raw = wave_raw + 2 * lane;
+    constexpr int RAW_SLOT = kRawChunk * P;           // bytes one wave stages per frame
+    constexpr int PIECES = P / 8;                     // DMA instructions per wave per frame
+    uint8_t* const wave_raw = raw_base + wave * (RAWD * RAW_SLOT);
 
     // Loop-invariant per-thread constants: twiddles, sign, window.
     cf tw[NPASS - 1][P - 1];
@@ -105,32 +120,77 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
         for (int a = 0; a < P; ++a) wsgn[a] = window[t + T * a] * sgn;
     }
     double acc[P];
+    float acc32[ACCB > 0 ? P : 1];
 #pragma unroll
     for (int a = 0; a < P; ++a) acc[a] = 0.0;
+    if constexpr (ACCB > 0) {
+#pragma unroll
+        for (int a = 0; a < P; ++a) acc32[a] = 0.0f;
+    }
 
     const long stride = static_cast<long>(gridDim.x) * FPW;
     long fb = static_cast<long>(blockIdx.x) * FPW;
-    if (fb < nframes) stage_raw<G, DMA>(stream, fb, nframes, wave_raw, wave, lane);
+    if (fb < nframes) {
+#pragma unroll
+        for (int d = 0; d < RAWD; ++d)
+            stage_raw<G, DMA>(stream, fb + d * stride, nframes, wave_raw + d * RAW_SLOT, wave, lane);
+    }
 
+    PhaseClock clk;
+    clk.start();
     for (int it = 0; fb < nframes; fb += stride, ++it) {
         const bool active = (fb + fs) < nframes;
         cf* const slab = slab_base + ((DBUF ? (it & 1) : 0) * FPW + fs) * G::LDS_CPX;
+        uint8_t* const ring_slot = wave_raw + (it % RAWD) * RAW_SLOT;
         cf x[P];
 
-        // this wave's raw bytes have landed (they are staged by the wave itself)
-        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // this frame's bytes have landed: every iteration issues exactly PIECES DMA
+        // instructions per wave, so all but the newest (RAWD-1) frames' worth are done
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RAWD - 1) * PIECES) : "memory");
         exchange_sync<false>();
-        phase_unpack<G, WINDOW>(lane_raw, sgn, wsgn, x);
+        RPF_STAMP(clk, 0);                       // waiting for the staged bytes
+        phase_unpack<G, WINDOW>(ring_slot + 2 * lane, sgn, wsgn, x);
+        // The slot is refilled next: its ds_read_u16 must have RETURNED first (a DMA
+        // that hits in L2/MALL can land before queued LDS reads execute -- seen as
+        // sporadic 1e-3 errors), so wait for this wave's LDS reads, not just issue.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         exchange_sync<false>();
-        // the raw reads are consumed: stage the next frame while this one computes
-        if (fb + stride < nframes) stage_raw<G, DMA>(stream, fb + stride, nframes, wave_raw, wave, lane);
+        RPF_STAMP(clk, 1);                       // unpack
+        // the slot has been consumed: refill it with the frame RAWD iterations ahead
+        stage_raw<G, DMA>(stream, fb + RAWD * stride, nframes, ring_slot, wave, lane);
 
         // single slab: every wave must be done with the previous frame's slab
         if constexpr (!DBUF) exchange_sync<BLOCK_SYNC>();
-        middle_passes<G, 1>(t, x, tw, slab);
+        RPF_STAMP(clk, 2);                       // DMA issue + top-of-frame barrier
+        middle_passes<G, 1>(t, x, tw, slab, clk); // slots 4J..4J+3: fetch, butterfly, store, sync
         phase_fetch<G, NPASS>(t, x, slab);
+        asm volatile("" : "+v"(x[0]));
+        RPF_STAMP(clk, 12);                      // last fetch
         phase_last<G>(x);
-        if (active) phase_accumulate(x, acc, P);
+        RPF_STAMP(clk, 13);                      // last butterfly
+        if constexpr (ACCB > 0) {
+            if (active) {
+#pragma unroll
+                for (int a = 0; a < P; ++a)
+                    acc32[a] = __builtin_fmaf(x[a].x, x[a].x, __builtin_fmaf(x[a].y, x[a].y, acc32[a]));
+            }
+            if ((it % ACCB) == ACCB - 1) {
+#pragma unroll
+                for (int a = 0; a < P; ++a) {
+                    acc[a] += static_cast<double>(acc32[a]);
+                    acc32[a] = 0.0f;
+                }
+            }
+        } else {
+            if (active) phase_accumulate(x, acc, P);
+        }
+        RPF_STAMP(clk, 14);                      // accumulate
+    }
+    clk.publish(lane);
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (clamped) prefetches
+    if constexpr (ACCB > 0) {
+#pragma unroll
+        for (int a = 0; a < P; ++a) acc[a] += static_cast<double>(acc32[a]);
     }
 
     // One partial spectrum per workgroup (the FPW frame slots are summed here);
@@ -148,12 +208,14 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
         stage[fs * SN + bin + (bin >> 4)] = acc[a];
     }
     exchange_sync<true>();
-    double* out = partial + static_cast<size_t>(blockIdx.x) * N;
     for (int bin = tid; bin < N; bin += WG) {
         double v = 0.0;
 #pragma unroll
         for (int k = 0; k < FPW; ++k) v += stage[k * SN + bin + (bin >> 4)];
-        out[bin] = v;
+        if constexpr (PF32)
+            reinterpret_cast<float*>(partial)[static_cast<size_t>(blockIdx.x) * N + bin] = static_cast<float>(v);
+        else
+            partial[static_cast<size_t>(blockIdx.x) * N + bin] = v;
     }
 }
 
@@ -198,7 +260,7 @@ __global__ __launch_bounds__(WG, OCC) void bluestein_kernel(const uint8_t* __res
             x[a] = cf{0.0f, 0.0f};
             if (active && n < N) {
                 const uint32_t iq = *reinterpret_cast<const uint16_t*>(frame + 2 * n);
-                const cf v = cf{byte_plus_2p23(iq & 0xffu), byte_plus_2p23(iq >> 8)} - (kTwo23 + 127.0f);
+                const cf v = iq_plus_2p23(iq) - (kTwo23 + 127.0f);
                 x[a] = cmul(v, g[n]);
             }
         }
@@ -247,8 +309,9 @@ __global__ __launch_bounds__(WG, OCC) void bluestein_kernel(const uint8_t* __res
 // the 16 group sums are added in group order.
 constexpr int RED_BINS = 16, RED_GROUPS = 16, RED_UNROLL = 8;
 
+template <typename PT>
 __global__ __launch_bounds__(RED_BINS* RED_GROUPS) void reduce_kernel(
-    const double* __restrict__ partial, int nslots, int N, double* __restrict__ out,
+    const PT* __restrict__ partial, int nslots, int N, double* __restrict__ out,
     int accumulate)
 {
     __shared__ double red[RED_GROUPS][RED_BINS + 1];
@@ -256,10 +319,10 @@ __global__ __launch_bounds__(RED_BINS* RED_GROUPS) void reduce_kernel(
     const int bin = blockIdx.x * RED_BINS + b;
     double s = 0.0;
     if (bin < N) {
-        const double* p = partial + bin;
+        const PT* p = partial + bin;
         int sl = g;
         for (; sl + (RED_UNROLL - 1) * RED_GROUPS < nslots; sl += RED_UNROLL * RED_GROUPS) {
-            double v[RED_UNROLL];
+            PT v[RED_UNROLL];
 #pragma unroll
             for (int u = 0; u < RED_UNROLL; ++u)
                 v[u] = p[static_cast<size_t>(sl + u * RED_GROUPS) * N];
@@ -283,34 +346,43 @@ using KernelFn = void (*)(const uint8_t*, long, const cf*, const float*, double*
 
 struct Variant {
     int N, vid, P, WG, fpw, lds_bytes;
+    bool partial_f32;
     KernelFn fn[2][2];   // [window][dma]
 };
 
 // OCC (OCCW for the windowed kernels) = waves per SIMD the register budget
 // must admit (= resident workgroups per CU x WG/256).  vid = tuning variant
 // (0 = the default for this N).
-template <int N, int P, int OCC, int OCCW = OCC, bool DBUF = false>
+template <int N, int P, int OCC, int OCCW = OCC, bool DBUF = false, int ACCB = 0, bool PF32 = false,
+          int RAWD = 2>
 Variant make_variant(int vid)
 {
     using G = Geom<N, P>;
     constexpr int WG = G::T >= 256 ? G::T : 256;
     constexpr int FPW = WG / G::T;
-    constexpr int LDS = FPW * ((DBUF ? 2 : 1) * G::LDS_CPX * (int)sizeof(cf) + 2 * N);
-    return Variant{N, vid, P, WG, FPW, LDS,
-                   {{fft_accum_kernel<G, WG, OCC, false, false, DBUF>,
-                     fft_accum_kernel<G, WG, OCC, false, true, DBUF>},
-                    {fft_accum_kernel<G, WG, OCCW, true, false, DBUF>,
-                     fft_accum_kernel<G, WG, OCCW, true, true, DBUF>}}};
+    constexpr int LDS = FPW * ((DBUF ? 2 : 1) * G::LDS_CPX * (int)sizeof(cf) + RAWD * 2 * N);
+    return Variant{N, vid, P, WG, FPW, LDS, PF32,
+                   {{fft_accum_kernel<G, WG, OCC, false, false, DBUF, ACCB, PF32, RAWD>,
+                     fft_accum_kernel<G, WG, OCC, false, true, DBUF, ACCB, PF32, RAWD>},
+                    {fft_accum_kernel<G, WG, OCCW, true, false, DBUF, ACCB, PF32, RAWD>,
+                     fft_accum_kernel<G, WG, OCCW, true, true, DBUF, ACCB, PF32, RAWD>}}};
 }
 
 const Variant kVariants[] = {
-    make_variant<64, 8, 4>(0),       make_variant<128, 8, 4>(0),   make_variant<256, 8, 4>(0),
-    make_variant<512, 8, 4>(0),      make_variant<1024, 16, 3>(0), make_variant<2048, 16, 3>(0),
-    make_variant<4096, 16, 3, 2>(0), make_variant<8192, 16, 2>(0),
+    make_variant<64, 8, 4, 4, false, 0, false, 4>(0),    make_variant<128, 8, 4, 4, false, 0, false, 4>(0),
+    make_variant<256, 8, 4, 4, false, 0, false, 4>(0),   make_variant<512, 8, 4, 4, false, 0, false, 4>(0),
+    make_variant<1024, 16, 3, 3, false, 0, false, 2>(0), make_variant<2048, 16, 3, 3, false, 0, false, 2>(0),
+    make_variant<4096, 16, 3, 2, false, 0, false, 2>(0), make_variant<8192, 16, 2, 2, false, 0, false, 2>(0),
     // tuning variants (RPF_FLAG_VARIANT(k))
-    make_variant<4096, 16, 2, 2, true>(1), make_variant<4096, 8, 4>(2), make_variant<4096, 8, 4, 4, true>(3),
-    make_variant<512, 16, 3>(1),           make_variant<1024, 8, 4>(1), make_variant<2048, 8, 4>(1),
-    make_variant<2048, 16, 2, 2, true>(2), make_variant<8192, 16, 2, 2, true>(1),
+    make_variant<4096, 16, 3, 2, false, 0, false, 1>(1),   // one frame ahead only
+    make_variant<4096, 16, 2, 2, false, 0, false, 4>(2),   // four frames ahead, 2 workgroups per CU
+    make_variant<4096, 16, 2, 2, true, 0, false, 2>(3),    // double-buffered slab (one barrier per frame)
+    make_variant<4096, 16, 2, 2, false, 8, true, 4>(4),    // f32 batch accumulate + f32 partials, 4 ahead
+    make_variant<4096, 8, 4, 4, false, 0, false, 2>(5),    // 8 points per lane, 512 threads
+    make_variant<512, 8, 4, 4, false, 0, false, 2>(1),     make_variant<512, 8, 4, 4, false, 0, false, 8>(2),
+    make_variant<512, 16, 3, 3, false, 0, false, 2>(3),
+    make_variant<1024, 8, 4, 4, false, 0, false, 4>(1),    make_variant<2048, 8, 4, 4, false, 0, false, 4>(1),
+    make_variant<8192, 16, 2, 2, false, 0, false, 1>(1),
 };
 
 const Variant* find_variant(int N, int vid)
@@ -352,6 +424,20 @@ const BluesteinVariant* find_bluestein(int M)
 
 bool kernel_supported(int N, int vid) { return find_variant(N, vid) != nullptr; }
 
+#ifdef RPF_PHASE_TIMING
+extern "C" int rpf_debug_phase_cycles(unsigned long long* out16, unsigned long long* waves, int reset)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * kPhaseSlots) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(waves, HIP_SYMBOL(g_phase_waves), sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[kPhaseSlots] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_waves), z, sizeof(unsigned long long));
+    }
+    return 0;
+}
+#endif
+
 hipError_t plan_launch(int N, int vid, bool window, bool use_dma, int device, LaunchInfo* li)
 {
     const Variant* v = find_variant(N, vid);
@@ -372,6 +458,7 @@ hipError_t plan_launch(int N, int vid, bool window, bool use_dma, int device, La
     li->block = v->WG;
     li->fpw = v->fpw;
     li->lds_bytes = v->lds_bytes;
+    li->partial_f32 = v->partial_f32;
     return hipSuccess;
 }
 
@@ -389,6 +476,7 @@ hipError_t launch_fft_accum(int N, int vid, bool window, bool use_dma, const uin
         li->block = v->WG;
         li->fpw = v->fpw;
         li->lds_bytes = v->lds_bytes;
+        li->partial_f32 = v->partial_f32;
     }
     return hipGetLastError();
 }
@@ -438,11 +526,15 @@ hipError_t launch_bluestein(int N, const uint8_t* d_stream, long nframes, const 
 }
 
 hipError_t launch_reduce(const double* d_partial, int nslots, int N, double* d_out,
-                         bool accumulate, hipStream_t stream)
+                         bool accumulate, hipStream_t stream, bool partial_f32)
 {
     const int blocks = (N + RED_BINS - 1) / RED_BINS;
-    hipLaunchKernelGGL(reduce_kernel, dim3(blocks), dim3(RED_BINS * RED_GROUPS), 0, stream,
-                       d_partial, nslots, N, d_out, accumulate ? 1 : 0);
+    if (partial_f32)
+        hipLaunchKernelGGL(reduce_kernel<float>, dim3(blocks), dim3(RED_BINS * RED_GROUPS), 0, stream,
+                           reinterpret_cast<const float*>(d_partial), nslots, N, d_out, accumulate ? 1 : 0);
+    else
+        hipLaunchKernelGGL(reduce_kernel<double>, dim3(blocks), dim3(RED_BINS * RED_GROUPS), 0, stream,
+                           d_partial, nslots, N, d_out, accumulate ? 1 : 0);
     return hipGetLastError();
 }
 
