@@ -86,7 +86,7 @@ __device__ __forceinline__ void stage_raw(const uint8_t* __restrict__ stream, lo
 // float32 (half the flush and K3 traffic; each partial is a sum over ~13 frames
 // and there are hundreds of them, so the rounding averages out to ~1e-9).
 template <class G, int WG, int OCC, bool WINDOW, bool DMA, bool DBUF, int ACCB = 0, bool PF32 = false,
-          int RAWD = 2>
+          int RAWD = 2, int ABL = 0, bool TWLDS = false>
 __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __restrict__ stream,
                                                             long nframes,
                                                             const cf* __restrict__ twN,
@@ -112,7 +112,12 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
 
     // Loop-invariant per-thread constants: twiddles, sign, window.
     cf tw[NPASS - 1][P - 1];
-    load_twiddles<G, 1>(t, twN, tw);
+    load_twiddles<G, 1, TWLDS>(t, twN, tw);
+    cf* const twtable = reinterpret_cast<cf*>(raw_base + (WG / 64) * RAWD * (kRawChunk * P));
+    if constexpr (TWLDS) {
+        fill_twlds<G, 1>(tid, WG, twN, twtable);
+        __syncthreads();
+    }
     const float sgn = (t & 1) ? -1.0f : 1.0f;
     float wsgn[P];
     if constexpr (WINDOW) {
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
 
         // this frame's bytes have landed: every iteration issues exactly PIECES DMA
         // instructions per wave, so all but the newest (RAWD-1) frames' worth are done
-        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RAWD - 1) * PIECES) : "memory");
+        if constexpr (DMA && !(ABL & 8)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RAWD - 1) * PIECES) : "memory");
         exchange_sync<false>();
         RPF_STAMP(clk, 0);                       // waiting for the staged bytes
         phase_unpack<G, WINDOW>(ring_slot + 2 * lane, sgn, wsgn, x);
@@ -157,16 +162,16 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
         exchange_sync<false>();
         RPF_STAMP(clk, 1);                       // unpack
         // the slot has been consumed: refill it with the frame RAWD iterations ahead
-        stage_raw<G, DMA>(stream, fb + RAWD * stride, nframes, ring_slot, wave, lane);
+        if constexpr (!(ABL & 8)) stage_raw<G, DMA>(stream, fb + RAWD * stride, nframes, ring_slot, wave, lane);
 
         // single slab: every wave must be done with the previous frame's slab
         if constexpr (!DBUF) exchange_sync<BLOCK_SYNC>();
         RPF_STAMP(clk, 2);                       // DMA issue + top-of-frame barrier
-        middle_passes<G, 1>(t, x, tw, slab, clk); // slots 4J..4J+3: fetch, butterfly, store, sync
-        phase_fetch<G, NPASS>(t, x, slab);
+        middle_passes<G, 1, ABL, TWLDS>(t, x, tw, slab, clk, twtable);   // stamps 4J..4J+3
+        if constexpr (!(ABL & 4)) phase_fetch<G, NPASS>(t, x, slab);
         asm volatile("" : "+v"(x[0]));
         RPF_STAMP(clk, 12);                      // last fetch
-        phase_last<G>(x);
+        if constexpr (!(ABL & 2)) phase_last<G>(x);
         RPF_STAMP(clk, 13);                      // last butterfly
         if constexpr (ACCB > 0) {
             if (active) {
@@ -181,6 +186,9 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
                     acc32[a] = 0.0f;
                 }
             }
+        } else if constexpr (ABL & 1) {
+#pragma unroll
+            for (int a = 0; a < P; ++a) asm volatile("" ::"v"(x[a]));
         } else {
             if (active) phase_accumulate(x, acc, P);
         }
@@ -354,35 +362,47 @@ struct Variant {
 // must admit (= resident workgroups per CU x WG/256).  vid = tuning variant
 // (0 = the default for this N).
 template <int N, int P, int OCC, int OCCW = OCC, bool DBUF = false, int ACCB = 0, bool PF32 = false,
-          int RAWD = 2>
+          int RAWD = 2, int ABL = 0, bool TWLDS = false>
 Variant make_variant(int vid)
 {
     using G = Geom<N, P>;
     constexpr int WG = G::T >= 256 ? G::T : 256;
     constexpr int FPW = WG / G::T;
-    constexpr int LDS = FPW * ((DBUF ? 2 : 1) * G::LDS_CPX * (int)sizeof(cf) + RAWD * 2 * N);
+    constexpr int LDS = FPW * ((DBUF ? 2 : 1) * G::LDS_CPX * (int)sizeof(cf) + RAWD * 2 * N) +
+                        (TWLDS ? twlds_entries<G>() * (int)sizeof(cf) : 0);
     return Variant{N, vid, P, WG, FPW, LDS, PF32,
-                   {{fft_accum_kernel<G, WG, OCC, false, false, DBUF, ACCB, PF32, RAWD>,
-                     fft_accum_kernel<G, WG, OCC, false, true, DBUF, ACCB, PF32, RAWD>},
-                    {fft_accum_kernel<G, WG, OCCW, true, false, DBUF, ACCB, PF32, RAWD>,
-                     fft_accum_kernel<G, WG, OCCW, true, true, DBUF, ACCB, PF32, RAWD>}}};
+                   {{fft_accum_kernel<G, WG, OCC, false, false, DBUF, ACCB, PF32, RAWD, ABL, TWLDS>,
+                     fft_accum_kernel<G, WG, OCC, false, true, DBUF, ACCB, PF32, RAWD, ABL, TWLDS>},
+                    {fft_accum_kernel<G, WG, OCCW, true, false, DBUF, ACCB, PF32, RAWD, ABL, TWLDS>,
+                     fft_accum_kernel<G, WG, OCCW, true, true, DBUF, ACCB, PF32, RAWD, ABL, TWLDS>}}};
 }
 
 const Variant kVariants[] = {
+    // defaults.  Template arguments after <N, P>: OCC, OCCW, DBUF, ACCB, PF32, RAWD, ABL, TWLDS
     make_variant<64, 8, 4, 4, false, 0, false, 4>(0),    make_variant<128, 8, 4, 4, false, 0, false, 4>(0),
-    make_variant<256, 8, 4, 4, false, 0, false, 4>(0),   make_variant<512, 8, 4, 4, false, 0, false, 4>(0),
-    make_variant<1024, 16, 3, 3, false, 0, false, 2>(0), make_variant<2048, 16, 3, 3, false, 0, false, 2>(0),
-    make_variant<4096, 16, 3, 2, false, 0, false, 2>(0), make_variant<8192, 16, 2, 2, false, 0, false, 2>(0),
-    // tuning variants (RPF_FLAG_VARIANT(k))
-    make_variant<4096, 16, 3, 2, false, 0, false, 1>(1),   // one frame ahead only
-    make_variant<4096, 16, 2, 2, false, 0, false, 4>(2),   // four frames ahead, 2 workgroups per CU
-    make_variant<4096, 16, 2, 2, true, 0, false, 2>(3),    // double-buffered slab (one barrier per frame)
-    make_variant<4096, 16, 2, 2, false, 8, true, 4>(4),    // f32 batch accumulate + f32 partials, 4 ahead
-    make_variant<4096, 8, 4, 4, false, 0, false, 2>(5),    // 8 points per lane, 512 threads
-    make_variant<512, 8, 4, 4, false, 0, false, 2>(1),     make_variant<512, 8, 4, 4, false, 0, false, 8>(2),
+    make_variant<256, 8, 4, 4, false, 0, false, 4>(0),   make_variant<512, 8, 4, 4, false, 0, false, 2>(0),
+    make_variant<1024, 16, 3, 2, false, 0, false, 2, 0, true>(0),
+    make_variant<2048, 16, 3, 2, false, 0, false, 2, 0, true>(0),
+    make_variant<4096, 16, 3, 2, false, 0, false, 2, 0, true>(0),
+    make_variant<8192, 16, 2, 2, false, 0, false, 2>(0),
+    // tuning variants (RPF_FLAG_VARIANT(k)); every one is exact unless it says float32
+    make_variant<4096, 16, 3, 2, false, 0, false, 2>(1),              // all twiddles in registers
+    make_variant<4096, 16, 3, 2, false, 0, false, 1, 0, true>(2),     // one frame ahead only
+    make_variant<4096, 16, 2, 2, true, 0, false, 2, 0, true>(3),      // double-buffered slab (one barrier per frame)
+    make_variant<4096, 16, 3, 3, false, 8, true, 2, 0, true>(4),      // float32 batch accumulate + float32 partials
+    make_variant<4096, 8, 4, 4, false, 0, false, 2>(5),               // 8 points per lane, 512 threads
+    make_variant<512, 8, 4, 4, false, 0, false, 4>(1),  make_variant<512, 8, 4, 4, false, 0, false, 8>(2),
     make_variant<512, 16, 3, 3, false, 0, false, 2>(3),
-    make_variant<1024, 8, 4, 4, false, 0, false, 4>(1),    make_variant<2048, 8, 4, 4, false, 0, false, 4>(1),
-    make_variant<8192, 16, 2, 2, false, 0, false, 1>(1),
+    make_variant<1024, 8, 4, 4, false, 0, false, 4>(1), make_variant<2048, 8, 4, 4, false, 0, false, 4>(1),
+    make_variant<1024, 16, 3, 3, false, 0, false, 2>(2), make_variant<2048, 16, 3, 3, false, 0, false, 2>(2),
+    make_variant<8192, 16, 2, 2, false, 0, false, 2, 0, true>(1),
+    // measurement-only ablations of the default N=4096 kernel (results are garbage)
+    make_variant<4096, 16, 3, 2, false, 0, false, 2, 1, true>(11),    // no accumulate
+    make_variant<4096, 16, 3, 2, false, 0, false, 2, 2, true>(12),    // no butterfly arithmetic
+    make_variant<4096, 16, 3, 2, false, 0, false, 2, 4, true>(13),    // no LDS exchanges
+    make_variant<4096, 16, 3, 2, false, 0, false, 2, 8, true>(14),    // no HBM staging
+    make_variant<4096, 16, 3, 2, false, 0, false, 2, 6, true>(15),    // no arithmetic, no exchanges
+    make_variant<4096, 16, 3, 2, false, 0, false, 2, 3, true>(16),    // no arithmetic at all
 };
 
 const Variant* find_variant(int N, int vid)

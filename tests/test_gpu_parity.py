@@ -78,7 +78,8 @@ def test_device_path_matches_golden_vectors(name, torch_dev):
     assert max_rel(host, got) < 1e-13        # queue path and device path run the same kernels
 
 
-@pytest.mark.parametrize("N,variant", [(4096, 1), (4096, 2), (512, 1), (1024, 1), (2048, 1)])
+@pytest.mark.parametrize("N,variant", [(4096, 1), (4096, 2), (4096, 3), (4096, 5), (512, 1), (512, 2),
+                                       (512, 3), (1024, 1), (1024, 2), (2048, 1), (2048, 2), (8192, 1)])
 def test_tuning_variants_agree(N, variant, torch_dev):
     R = 40
     stream = rpf.synth.uniform_iq(3, N * R)
