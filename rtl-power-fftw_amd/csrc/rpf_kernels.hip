@@ -40,6 +40,19 @@ namespace rpf {
 
 namespace {
 
+// One 16-byte piece of the frame data a lane stages (same mapping as stage_raw),
+// loaded into registers.
+template <class G>
+__device__ __forceinline__ uint4 load_raw_piece(const uint8_t* __restrict__ stream, long fb, long nframes,
+                                                int wave, int lane, int i)
+{
+    int slot, off;
+    raw_source<G>(wave, i * 1024 + lane * 16, &slot, &off);
+    long f = fb + slot;
+    f = f < nframes ? f : nframes - 1;
+    return *reinterpret_cast<const uint4*>(stream + f * (2 * G::N) + off);
+}
+
 // Stage the raw bytes this wavefront will unpack in the iteration whose slot-0
 // frame is `fb` (wave-local, a-major layout: fft_core.h raw_source).  P/8
 // instructions per wave, each moving 64 lanes x 16 B = eight 128-byte rows.
@@ -86,7 +99,7 @@ __device__ __forceinline__ void stage_raw(const uint8_t* __restrict__ stream, lo
 // float32 (half the flush and K3 traffic; each partial is a sum over ~13 frames
 // and there are hundreds of them, so the rounding averages out to ~1e-9).
 template <class G, int WG, int OCC, bool WINDOW, bool DMA, bool DBUF, int ACCB = 0, bool PF32 = false,
-          int RAWD = 2, int ABL = 0, bool TWLDS = false>
+          int RAWD = 2, int ABL = 0, bool TWLDS = false, bool RAWREG = false>
 __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __restrict__ stream,
                                                             long nframes,
                                                             const cf* __restrict__ twN,
@@ -110,13 +123,31 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
     constexpr int PIECES = P / 8;                     // DMA instructions per wave per frame
     uint8_t* const wave_raw = raw_base + wave * (RAWD * RAW_SLOT);
 
+    // First thing: get the first frames' bytes moving (HBM latency overlaps the
+    // constant loads below).  RAWREG keeps the next frame's 2P bytes per lane in
+    // VGPRs instead of issuing LDS-DMA (two global_load_dwordx4 cost a few issue
+    // cycles, an LDS-DMA instruction ~100-200).
+    const long stride = static_cast<long>(gridDim.x) * FPW;
+    long fb = static_cast<long>(blockIdx.x) * FPW;
+    uint4 pre[RAWREG ? PIECES : 1];
+    if (fb < nframes) {
+        if constexpr (RAWREG) {
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) pre[i] = load_raw_piece<G>(stream, fb, nframes, wave, lane, i);
+        } else {
+#pragma unroll
+            for (int d = 0; d < RAWD; ++d)
+                stage_raw<G, DMA>(stream, fb + d * stride, nframes, wave_raw + d * RAW_SLOT, wave, lane);
+        }
+    }
+
     // Loop-invariant per-thread constants: twiddles, sign, window.
     cf tw[NPASS - 1][P - 1];
     load_twiddles<G, 1, TWLDS>(t, twN, tw);
     cf* const twtable = reinterpret_cast<cf*>(raw_base + (WG / 64) * RAWD * (kRawChunk * P));
     if constexpr (TWLDS) {
         fill_twlds<G, 1>(tid, WG, twN, twtable);
-        __syncthreads();
+        exchange_sync<true>();
     }
     const float sgn = (t & 1) ? -1.0f : 1.0f;
     float wsgn[P];
@@ -133,14 +164,6 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
         for (int a = 0; a < P; ++a) acc32[a] = 0.0f;
     }
 
-    const long stride = static_cast<long>(gridDim.x) * FPW;
-    long fb = static_cast<long>(blockIdx.x) * FPW;
-    if (fb < nframes) {
-#pragma unroll
-        for (int d = 0; d < RAWD; ++d)
-            stage_raw<G, DMA>(stream, fb + d * stride, nframes, wave_raw + d * RAW_SLOT, wave, lane);
-    }
-
     PhaseClock clk;
     clk.start();
     for (int it = 0; fb < nframes; fb += stride, ++it) {
@@ -149,20 +172,38 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
         uint8_t* const ring_slot = wave_raw + (it % RAWD) * RAW_SLOT;
         cf x[P];
 
-        // this frame's bytes have landed: every iteration issues exactly PIECES DMA
-        // instructions per wave, so all but the newest (RAWD-1) frames' worth are done
-        if constexpr (DMA && !(ABL & 8)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RAWD - 1) * PIECES) : "memory");
-        exchange_sync<false>();
-        RPF_STAMP(clk, 0);                       // waiting for the staged bytes
-        phase_unpack<G, WINDOW>(ring_slot + 2 * lane, sgn, wsgn, x);
-        // The slot is refilled next: its ds_read_u16 must have RETURNED first (a DMA
-        // that hits in L2/MALL can land before queued LDS reads execute -- seen as
-        // sporadic 1e-3 errors), so wait for this wave's LDS reads, not just issue.
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        exchange_sync<false>();
-        RPF_STAMP(clk, 1);                       // unpack
-        // the slot has been consumed: refill it with the frame RAWD iterations ahead
-        if constexpr (!(ABL & 8)) stage_raw<G, DMA>(stream, fb + RAWD * stride, nframes, ring_slot, wave, lane);
+        if constexpr (RAWREG) {
+            // this frame's bytes sit in VGPRs: drop them into the wave's raw slot, then
+            // start the loads of the next frame into the same registers
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) *reinterpret_cast<uint4*>(ring_slot + i * 1024 + lane * 16) = pre[i];
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) pre[i] = load_raw_piece<G>(stream, fb + stride, nframes, wave, lane, i);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            exchange_sync<false>();
+            RPF_STAMP(clk, 0);
+            phase_unpack<G, WINDOW>(ring_slot + 2 * lane, sgn, wsgn, x);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            exchange_sync<false>();
+            RPF_STAMP(clk, 1);
+        } else {
+            // this frame's bytes have landed: every iteration issues exactly PIECES DMA
+            // instructions per wave, so all but the newest (RAWD-1) frames' worth are done
+            if constexpr (DMA && !(ABL & 8))
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RAWD - 1) * PIECES) : "memory");
+            exchange_sync<false>();
+            RPF_STAMP(clk, 0);                   // waiting for the staged bytes
+            phase_unpack<G, WINDOW>(ring_slot + 2 * lane, sgn, wsgn, x);
+            // The slot is refilled next: its ds_read_u16 must have RETURNED first (a DMA
+            // that hits in L2/MALL can land before queued LDS reads execute -- seen as
+            // sporadic 1e-3 errors), so wait for this wave's LDS reads, not just issue.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            exchange_sync<false>();
+            RPF_STAMP(clk, 1);                   // unpack
+            // the slot has been consumed: refill it with the frame RAWD iterations ahead
+            if constexpr (!(ABL & 8))
+                stage_raw<G, DMA>(stream, fb + RAWD * stride, nframes, ring_slot, wave, lane);
+        }
 
         // single slab: every wave must be done with the previous frame's slab
         if constexpr (!DBUF) exchange_sync<BLOCK_SYNC>();
@@ -362,7 +403,7 @@ struct Variant {
 // must admit (= resident workgroups per CU x WG/256).  vid = tuning variant
 // (0 = the default for this N).
 template <int N, int P, int OCC, int OCCW = OCC, bool DBUF = false, int ACCB = 0, bool PF32 = false,
-          int RAWD = 2, int ABL = 0, bool TWLDS = false>
+          int RAWD = 2, int ABL = 0, bool TWLDS = false, bool RAWREG = false>
 Variant make_variant(int vid)
 {
     using G = Geom<N, P>;
@@ -371,10 +412,10 @@ Variant make_variant(int vid)
     constexpr int LDS = FPW * ((DBUF ? 2 : 1) * G::LDS_CPX * (int)sizeof(cf) + RAWD * 2 * N) +
                         (TWLDS ? twlds_entries<G>() * (int)sizeof(cf) : 0);
     return Variant{N, vid, P, WG, FPW, LDS, PF32,
-                   {{fft_accum_kernel<G, WG, OCC, false, false, DBUF, ACCB, PF32, RAWD, ABL, TWLDS>,
-                     fft_accum_kernel<G, WG, OCC, false, true, DBUF, ACCB, PF32, RAWD, ABL, TWLDS>},
-                    {fft_accum_kernel<G, WG, OCCW, true, false, DBUF, ACCB, PF32, RAWD, ABL, TWLDS>,
-                     fft_accum_kernel<G, WG, OCCW, true, true, DBUF, ACCB, PF32, RAWD, ABL, TWLDS>}}};
+                   {{fft_accum_kernel<G, WG, OCC, false, false, DBUF, ACCB, PF32, RAWD, ABL, TWLDS, RAWREG>,
+                     fft_accum_kernel<G, WG, OCC, false, true, DBUF, ACCB, PF32, RAWD, ABL, TWLDS, RAWREG>},
+                    {fft_accum_kernel<G, WG, OCCW, true, false, DBUF, ACCB, PF32, RAWD, ABL, TWLDS, RAWREG>,
+                     fft_accum_kernel<G, WG, OCCW, true, true, DBUF, ACCB, PF32, RAWD, ABL, TWLDS, RAWREG>}}};
 }
 
 const Variant kVariants[] = {
@@ -391,6 +432,8 @@ const Variant kVariants[] = {
     make_variant<4096, 16, 2, 2, true, 0, false, 2, 0, true>(3),      // double-buffered slab (one barrier per frame)
     make_variant<4096, 16, 3, 3, false, 8, true, 2, 0, true>(4),      // float32 batch accumulate + float32 partials
     make_variant<4096, 8, 4, 4, false, 0, false, 2>(5),               // 8 points per lane, 512 threads
+    make_variant<4096, 16, 3, 2, false, 0, false, 1, 0, true, true>(6),   // next frame prefetched in VGPRs, no LDS-DMA
+    make_variant<4096, 16, 3, 3, false, 8, true, 1, 0, true, true>(7),    // same + float32 batch accumulate/partials
     make_variant<512, 8, 4, 4, false, 0, false, 4>(1),  make_variant<512, 8, 4, 4, false, 0, false, 8>(2),
     make_variant<512, 16, 3, 3, false, 0, false, 2>(3),
     make_variant<1024, 8, 4, 4, false, 0, false, 4>(1), make_variant<2048, 8, 4, 4, false, 0, false, 4>(1),
