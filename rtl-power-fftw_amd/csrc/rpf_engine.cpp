@@ -312,7 +312,7 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
     if (!fourstep && !bluestein && !rpf::kernel_supported(cfg->N, variant))
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT,
                     "No gfx950 kernel for " + std::to_string(cfg->N) +
-                        " bins in this build (supported: every even N up to 2048, 4096, 8192 and 262144).");
+                        " bins in this build (supported: every even N up to 4096, 8192 and 262144).");
     if (cfg->n_buffers < 1)
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT, "Argument to 'buffers' must be a positive number.");
     if (cfg->buffer_capacity < 2 || (cfg->buffer_capacity % 2) != 0)

@@ -39,7 +39,7 @@ hipError_t launch_fft_accum(int N, int vid, bool window, bool use_dma, const uin
 hipError_t launch_reduce(const double* d_partial, int nslots, int N, double* d_out,
                          bool accumulate, hipStream_t stream, bool partial_f32 = false);
 
-// ---- Bluestein path (KB in rpf_kernels.hip): any other even N <= 2048 ----------
+// ---- Bluestein path (KB in rpf_kernels.hip): any other even N <= 4096 ----------
 bool bluestein_supported(int N);
 hipError_t plan_bluestein(int N, int device, LaunchInfo* li);
 // d_twM: master twiddles of length M = bluestein_length(N); d_g / d_bhat: bluestein_tables.h

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
     }
 }
 
-// KB  bluestein_kernel -- any even N <= 2048 that is not one of K1's powers of two
+// KB  bluestein_kernel -- any even N <= 4096 that is not one of K1's powers of two
 // (bluestein_tables.h).  G = Geom<M, P> with M = 2^ceil(log2(2N-1)); per frame:
 //   a[n] = (v[n] - 127) * g[n] for n < N, zero-padded to M      (g carries (-1)^n, window, chirp)
 //   A = FFT_M(a);  z = conj(A * bhat);  c = FFT_M(z)            (= conj of the circular convolution)
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
 // The two transforms reuse K1's passes; between them the spectrum goes through
 // the slab once more (digit-reversed -> natural order).  Samples are read
 // straight from HBM as coalesced u16 loads (frames are only 4-byte aligned).
-template <class G, int WG, int OCC>
+template <class G, int WG, int OCC, bool TWLDS>
 __global__ __launch_bounds__(WG, OCC) void bluestein_kernel(const uint8_t* __restrict__ stream,
                                                             long nframes, int N,
                                                             const cf* __restrict__ twM,
@@ -293,7 +293,13 @@ __global__ __launch_bounds__(WG, OCC) void bluestein_kernel(const uint8_t* __res
     cf* const slab = reinterpret_cast<cf*>(smem) + fs * G::LDS_CPX;
 
     cf tw[NPASS - 1][P - 1];
-    load_twiddles<G, 1>(t, twM, tw);
+    load_twiddles<G, 1, TWLDS>(t, twM, tw);
+    cf* const twtable = reinterpret_cast<cf*>(smem) + FPW * G::LDS_CPX;
+    if constexpr (TWLDS) {
+        fill_twlds<G, 1>(tid, WG, twM, twtable);
+        exchange_sync<true>();
+    }
+    PhaseClock noclk;
     double acc[P];
 #pragma unroll
     for (int a = 0; a < P; ++a) acc[a] = 0.0;
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(WG, OCC) void bluestein_kernel(const uint8_t* __res
             }
         }
         exchange_sync<BLOCK_SYNC>();             // previous frame's slab reads are done
-        middle_passes<G, 1>(t, x, tw, slab);
+        middle_passes<G, 1, 0, TWLDS>(t, x, tw, slab, noclk, twtable);
         phase_fetch<G, NPASS>(t, x, slab);
         phase_last<G>(x);
         exchange_sync<BLOCK_SYNC>();             // ... before the slab is rewritten in another order
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(WG, OCC) void bluestein_kernel(const uint8_t* __res
         }
         exchange_sync<BLOCK_SYNC>();
         phase_fetch<G, 1>(t, x, slab);           // natural order: lane t gets elements t + T a
-        middle_passes<G, 1>(t, x, tw, slab);     // its pass-1 store rewrites exactly those slots
+        middle_passes<G, 1, 0, TWLDS>(t, x, tw, slab, noclk, twtable);   // its pass-1 store rewrites exactly those slots
         phase_fetch<G, NPASS>(t, x, slab);
         phase_last<G>(x);
         if (active) phase_accumulate(x, acc, P);
@@ -460,21 +466,22 @@ struct BluesteinVariant {
     int M, WG, fpw, lds_bytes;
     BluesteinFn fn;
 };
-template <int M, int P, int OCC>
+template <int M, int P, int OCC, bool TWLDS = false>
 BluesteinVariant make_bluestein()
 {
     using G = Geom<M, P>;
     constexpr int WG = G::T >= 256 ? G::T : 256;
     constexpr int FPW = WG / G::T;
-    return BluesteinVariant{M, WG, FPW, FPW * G::LDS_CPX * (int)sizeof(cf), bluestein_kernel<G, WG, OCC>};
+    constexpr int LDS = FPW * G::LDS_CPX * (int)sizeof(cf) + (TWLDS ? twlds_entries<G>() * (int)sizeof(cf) : 0);
+    return BluesteinVariant{M, WG, FPW, LDS, bluestein_kernel<G, WG, OCC, TWLDS>};
 }
 const BluesteinVariant kBluestein[] = {
     make_bluestein<64, 8, 4>(),    make_bluestein<128, 8, 4>(),   make_bluestein<256, 8, 4>(),
-    // P = 8 throughout (two inlined transforms per frame: 16 points per lane
-    // spills even at 256 registers); M = 8192 would need 1024-thread workgroups
-    // capped at 128 registers, so Bluestein stops at N = 2048 (M = 4096).
+    // P = 8 up to M = 4096 (two inlined transforms per frame: 16 points per lane
+    // with register twiddles spills even at 256 registers); M = 8192 (N up to
+    // 4096) runs 16 points per lane with the pass-2/3 twiddles in an LDS table.
     make_bluestein<512, 8, 4>(),   make_bluestein<1024, 8, 2>(),  make_bluestein<2048, 8, 2>(),
-    make_bluestein<4096, 8, 2>(),
+    make_bluestein<4096, 8, 2>(),  make_bluestein<8192, 16, 2, true>(),
 };
 const BluesteinVariant* find_bluestein(int M)
 {
@@ -546,7 +553,7 @@ hipError_t launch_fft_accum(int N, int vid, bool window, bool use_dma, const uin
 
 bool bluestein_supported(int N)
 {
-    return N >= 2 && N % 2 == 0 && N <= 2048 && !kernel_supported(N, 0) &&
+    return N >= 2 && N % 2 == 0 && N <= 4096 && !kernel_supported(N, 0) &&
            find_bluestein(bluestein_length(N)) != nullptr;
 }
 

@@ -38,7 +38,7 @@ def test_emulated_kernel_bin_placement(N, P):
     assert np.sort(got)[-2] < 1e-3 * got.max()
 
 
-@pytest.mark.parametrize("N", [2, 6, 30, 32, 100, 500, 1000, 1536, 2046])
+@pytest.mark.parametrize("N", [2, 6, 30, 32, 100, 500, 1000, 1536, 2046, 3000, 4094])
 @pytest.mark.parametrize("windowed", [False, True])
 def test_emulated_bluestein_kernel_matches_oracle(N, windowed):
     """Sizes that are not powers of two (the man page's -b 500 among them) go

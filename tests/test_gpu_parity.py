@@ -91,10 +91,10 @@ def test_tuning_variants_agree(N, variant, torch_dev):
     assert max_rel(pb, truth_f64(N, stream, R)) < VS_TRUTH
 
 
-@pytest.mark.parametrize("N", [2, 6, 30, 32, 100, 500, 1000, 1536, 2046])
+@pytest.mark.parametrize("N", [2, 6, 30, 32, 100, 500, 1000, 1536, 2046, 3000, 4094])
 @pytest.mark.parametrize("windowed", [False, True])
 def test_non_power_of_two_sizes_match_oracle(N, windowed, torch_dev):
-    """Any even N up to 2048 (the reference takes any even N because FFTW does;
+    """Any even N up to 4096 (the reference takes any even N because FFTW does;
     the man page's example is -b 500): Bluestein kernel, device and queue paths."""
     R = 61
     stream = rpf.synth.uniform_iq(900 + N, N * R + 7 * N // 2)
