@@ -86,7 +86,8 @@ struct rpf_engine {
     bool bluestein = false;               // N handled by the Bluestein kernel (chirp tables below)
     rpf::cf* d_chirp = nullptr;           // g[n], N entries
     rpf::cf* d_bhat = nullptr;            // frequency-domain chirp, M entries
-    rpf::cf* d_tw_sub = nullptr;          // four-step: W_512 table of the sub-transforms
+    rpf::cf* d_tw_sub = nullptr;          // four-step: twiddles of the N1-point column transforms
+    rpf::cf* d_tw_sub2 = nullptr;         // four-step: twiddles of the N2-point row transforms
     rpf::cf* d_scratch = nullptr;         // four-step: intermediate Y
     float* d_window = nullptr;
     double* d_partial = nullptr;
@@ -127,8 +128,8 @@ int launch_transform(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, hi
     if (e->fourstep) {
         const bool dma = e->use_dma && (addr % 4) == 0;
         HIP_TRY(e, rpf::launch_fourstep(e->N, e->has_window, dma, d_frames, nframes, e->d_tw_sub,
-                                        e->d_twiddles, e->d_window, e->d_scratch, e->d_partial,
-                                        e->plan.grid, stream));
+                                        e->d_tw_sub2, e->d_twiddles, e->d_window, e->d_scratch,
+                                        e->d_partial, e->plan.grid, stream));
         e->last = e->plan;
         *nslots = rpf::fourstep_partial_slots(e->N);
         return RPF_OK;
@@ -267,6 +268,7 @@ void release_device(rpf_engine* e)
 {
     if (e->d_twiddles) (void)hipFree(e->d_twiddles);
     if (e->d_tw_sub) (void)hipFree(e->d_tw_sub);
+    if (e->d_tw_sub2) (void)hipFree(e->d_tw_sub2);
     if (e->d_scratch) (void)hipFree(e->d_scratch);
     if (e->d_chirp) (void)hipFree(e->d_chirp);
     if (e->d_bhat) (void)hipFree(e->d_bhat);
@@ -312,7 +314,7 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
     if (!fourstep && !bluestein && !rpf::kernel_supported(cfg->N, variant))
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT,
                     "No gfx950 kernel for " + std::to_string(cfg->N) +
-                        " bins in this build (supported: every even N up to 4096, 8192 and 262144).");
+                        " bins in this build (supported: every even N up to 4096 and the powers of two up to 262144).");
     if (cfg->n_buffers < 1)
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT, "Argument to 'buffers' must be a positive number.");
     if (cfg->buffer_capacity < 2 || (cfg->buffer_capacity % 2) != 0)
@@ -381,10 +383,15 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         partial_slots = e->plan.grid;
     } else if (e->fourstep) {
         CREATE_TRY(rpf::fourstep_prepare(e->N, e->device, &e->plan));
+        int n1 = 0, n2 = 0;
+        rpf::fourstep_sub_lengths(e->N, &n1, &n2);
         std::vector<rpf::cf> tws;
-        rpf::make_twiddles(512, tws);
+        rpf::make_twiddles(n1, tws);
         CREATE_TRY(hipMalloc(&e->d_tw_sub, sizeof(rpf::cf) * tws.size()));
         CREATE_TRY(hipMemcpy(e->d_tw_sub, tws.data(), sizeof(rpf::cf) * tws.size(), hipMemcpyHostToDevice));
+        rpf::make_twiddles(n2, tws);
+        CREATE_TRY(hipMalloc(&e->d_tw_sub2, sizeof(rpf::cf) * tws.size()));
+        CREATE_TRY(hipMemcpy(e->d_tw_sub2, tws.data(), sizeof(rpf::cf) * tws.size(), hipMemcpyHostToDevice));
         CREATE_TRY(hipMalloc(&e->d_scratch, rpf::fourstep_scratch_bytes(e->N)));
         partial_slots = rpf::fourstep_partial_slots(e->N);
     } else {

@@ -1,25 +1,27 @@
 // rpf_fourstep.hip -- gfx950 kernels for transform lengths that do not fit one
-// workgroup's LDS (config C4 of BASELINE.json: N = 262144 bins).
+// workgroup's LDS: N = N1*N2 with N1, N2 in {128, 256, 512}, i.e. the powers of
+// two 16384 ... 262144 (config C4 of BASELINE.json is N = 262144 = 512 x 512).
 //
-// Four-step decomposition, N = N1*N2 = 512*512, n = 512 n1 + n2, k = k1 + 512 k2:
+// Four-step decomposition, n = N2 n1 + n2, k = k1 + N1 k2:
 //
-//   X[k1 + 512 k2] = sum_{n2} W_512^{n2 k2} * ( W_N^{n2 k1} * sum_{n1} x[512 n1 + n2] W_512^{n1 k1} )
+//   X[k1 + N1 k2] = sum_{n2} W_N2^{n2 k2} * ( W_N^{n2 k1} * sum_{n1} x[N2 n1 + n2] W_N1^{n1 k1} )
 //
 //   K2a fourstep_cols_kernel  for a tile of 64 columns n2: the raw u8 rows (128 B =
 //        one cache line per n1) are staged in LDS by dword LDS-DMA into rows padded to
-//        33 dwords (conflict-free column reads); each wavefront runs 512-point
-//        column FFTs (8 points per lane, two wave-local LDS exchanges, no
+//        33 dwords (conflict-free column reads); every wavefront runs N1-point
+//        column FFTs -- 8 points per lane, so N1/8 lanes per column and 512/N1
+//        columns side by side in one wave -- with wave-local LDS exchanges (no
 //        s_barrier), multiplies by W_N^{n2 k1} and writes Y[frame][n2][k1] as
-//        coalesced 512-byte rows.  (-1)^n = (-1)^n2 is a per-column constant.
-//   K2b fourstep_rows_kernel  workgroup (k1 tile of 16 rows, frame group): loads the
-//        [512 n2][16 k1] tile of Y (one full cache line per n2), each wavefront owns
-//        one row k1 for the whole launch: 512-point FFT over n2, |X|^2 into 8
-//        per-lane f64 register accumulators; at the end the 16 rows of a tile leave
-//        as whole 128-byte lines of the per-frame-group partial spectrum.
+//        coalesced rows.  (-1)^n = (-1)^n2 is a per-column constant.
+//   K2b fourstep_rows_kernel  workgroup (k1 tile of 16*(512/N2) rows, frame group):
+//        loads the [N2 n2][tile k1] slab of Y (whole 128-byte lines), every
+//        wavefront owns 512/N2 rows for the whole launch: N2-point FFT over n2,
+//        |X|^2 into 8 per-lane f64 register accumulators; at the end the rows of a
+//        tile leave as whole 128-byte lines of the per-frame-group partial spectrum.
 //   K3  (rpf_kernels.hip) sums the frame-group partials into pwr.
 //
-// HBM/L2 traffic per frame: 0.5 MB raw (algorithmic) + 2 MB Y written + 2 MB Y read
-// + 2 MB of W_N twiddles (L2-resident table); frames are processed in batches
+// HBM/L2 traffic per sample: 2 B raw (algorithmic) + 8 B Y written + 8 B Y read
+// + 8 B of W_N twiddles (L2-resident table); frames are processed in batches
 // whose Y scratch (128 MB) stays inside the 256 MB Infinity Cache.
 #include <hip/hip_runtime.h>
 
@@ -32,62 +34,80 @@ namespace rpf {
 
 namespace {
 
-using G1 = Geom<512, 8>;              // the 512-point sub-transform: one wavefront, 8 points per lane
-constexpr int kN1 = 512, kN2 = 512, kNBig = kN1 * kN2;
 constexpr int kWG = 1024, kWaves = kWG / 64;
 constexpr int kColTile = 64;          // columns per K2a tile (128 raw bytes per row)
 constexpr int kRowDwords = 33;        // 32 data dwords + 1 pad per staged raw row
-constexpr int kRowTile = 16;          // k1 rows per K2b tile (128 B of Y per n2)
-constexpr int kRowPitch = kRowTile + 1;
-constexpr int kFrameGroups = 8;       // K2b: frames f = fg mod 8 share a workgroup's accumulators
-constexpr int kSlab = G1::LDS_CPX;    // 576 complex per wavefront
+constexpr size_t kScratchBytes = 128u << 20;
 
-constexpr int kColsLds = kN1 * kRowDwords * 4 + kWaves * kSlab * (int)sizeof(cf);            // 141312
-constexpr int kRowsLds = kN2 * kRowPitch * (int)sizeof(cf) + kWaves * kSlab * (int)sizeof(cf);  // 143360
+// Everything that depends on the factorisation N = N1 * N2.
+template <int N1_, int N2_>
+struct Split {
+    static constexpr int N1 = N1_, N2 = N2_, N = N1_ * N2_;
+    using GA = Geom<N1, 8>;                       // column transform (over n1)
+    using GB = Geom<N2, 8>;                       // row transform (over n2)
+    static constexpr int SUBA = 64 / GA::T;       // columns one wave transforms side by side
+    static constexpr int SUBB = 64 / GB::T;       // rows one wave transforms side by side
+    static constexpr int COLS_PER_WAVE = kColTile / kWaves;             // 4
+    static constexpr int ROW_TILE = 16 * SUBB;    // k1 rows per K2b workgroup
+    static constexpr int ROW_PITCH = ROW_TILE + 1;
+    static constexpr int ROW_TILES = N1 / ROW_TILE;
+    static constexpr int SLAB_A = SUBA * GA::LDS_CPX;                   // complex per wave
+    static constexpr int SLAB_B = SUBB * GB::LDS_CPX;
+    static constexpr int COLS_LDS = N1 * kRowDwords * 4 + kWaves * SLAB_A * (int)sizeof(cf);
+    static constexpr int ROWS_LDS = N2 * ROW_PITCH * (int)sizeof(cf) + kWaves * SLAB_B * (int)sizeof(cf);
+    static constexpr int BATCH = (int)(kScratchBytes / (sizeof(cf) * (size_t)N));   // frames per launch pair
+    static constexpr int GROUPS = (256 / ROW_TILES) < BATCH ? (256 / ROW_TILES) : BATCH;   // frame groups
+    static_assert(GA::T <= 64 && GB::T <= 64 && COLS_PER_WAVE % SUBA == 0, "");
+    static_assert(COLS_LDS <= 160 * 1024 && ROWS_LDS <= 160 * 1024, "");
+};
 
-// 512-point FFT of the 8 values per lane (pass-1 layout: lane t holds elements
-// t + 64 a); leaves X[bin_of<G1>(t, a)] in register a.
-__device__ __forceinline__ void wave_fft512(int t, cf* x, const cf (&tw)[G1::NPASS - 1][G1::P - 1],
-                                            cf* slab)
+// N-point FFT (G = Geom<N, 8>) of the 8 values per lane of a T-lane group (pass-1
+// layout: lane t holds elements t + T a); leaves X[bin_of<G>(t, a)] in register a.
+template <class G>
+__device__ __forceinline__ void group_fft(int t, cf* x, const cf (&tw)[G::NPASS - 1][G::P - 1], cf* slab)
 {
-    middle_passes<G1, 1>(t, x, tw, slab);
-    phase_fetch<G1, G1::NPASS>(t, x, slab);
-    phase_last<G1>(x);
+    middle_passes<G, 1>(t, x, tw, slab);
+    phase_fetch<G, G::NPASS>(t, x, slab);
+    phase_last<G>(x);
 }
 
-template <bool WINDOW, bool DMA>
+template <class S, bool WINDOW, bool DMA>
 __global__ __launch_bounds__(kWG, 4) void fourstep_cols_kernel(const uint8_t* __restrict__ stream,
                                                               int nframes,
-                                                              const cf* __restrict__ tw512,
+                                                              const cf* __restrict__ tw_sub,
                                                               const cf* __restrict__ twN,
                                                               const float* __restrict__ window,
                                                               cf* __restrict__ Y)
 {
+    using G = typename S::GA;
+    constexpr int N1 = S::N1, N2 = S::N2, T = G::T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint8_t* const raw = smem;                                                 // [512][33] dwords
-    cf* const slabs = reinterpret_cast<cf*>(smem + kN1 * kRowDwords * 4);      // [16][576]
+    uint8_t* const raw = smem;                                                 // [N1][33] dwords
+    cf* const slabs = reinterpret_cast<cf*>(smem + N1 * kRowDwords * 4);       // [16][SLAB_A]
 
     const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), t = tid & 63;
-    cf* const slab = slabs + wave * kSlab;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int sub = lane / T, t = lane % T;
+    cf* const slab = slabs + wave * S::SLAB_A + sub * G::LDS_CPX;
 
-    cf tw[G1::NPASS - 1][G1::P - 1];
-    load_twiddles<G1, 1>(t, tw512, tw);
+    cf tw[G::NPASS - 1][G::P - 1];
+    load_twiddles<G, 1>(t, tw_sub, tw);
 
-    const int ntasks = nframes * (kN2 / kColTile);
+    constexpr int TILES = N2 / kColTile;
+    const int ntasks = nframes * TILES;
 #pragma unroll 1
     for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
-        const int f = task / (kN2 / kColTile), ct = task % (kN2 / kColTile);
-        const uint8_t* const frame = stream + static_cast<size_t>(f) * (2 * kNBig);
+        const int f = task / TILES, ct = task % TILES;
+        const uint8_t* const frame = stream + static_cast<size_t>(f) * (2 * S::N);
 
         __syncthreads();   // the previous tile has been consumed by every wave
-        // stage the [512 rows][128 B] raw tile: LDS dword L <- row L/33, dword L%33
+        // stage the [N1 rows][128 B] raw tile: LDS dword L <- row L/33, dword L%33
 #pragma unroll 1
-        for (int i = 0; i < (kN1 * kRowDwords + kWG - 1) / kWG; ++i) {
+        for (int i = 0; i < (N1 * kRowDwords + kWG - 1) / kWG; ++i) {
             const int L = i * kWG + tid;
             const int r = L / kRowDwords, d = L % kRowDwords;
-            if (L < kN1 * kRowDwords && d < 32) {
-                const uint8_t* src = frame + 2 * (static_cast<size_t>(kN2) * r + kColTile * ct) + 4 * d;
+            if (L < N1 * kRowDwords && d < 32) {
+                const uint8_t* src = frame + 2 * (static_cast<size_t>(N2) * r + kColTile * ct) + 4 * d;
                 if constexpr (DMA) {
                     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(raw + 4 * (i * kWG + wave * 64)),
                                                      4, 0, 0);
@@ -102,163 +122,207 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_cols_kernel(const uint8_t* __
         __syncthreads();
 
 #pragma unroll 1
-        for (int j = 0; j < kColTile / kWaves; ++j) {
-            const int cl = wave + kWaves * j;           // column inside the tile
-            const int c = kColTile * ct + cl;           // n2
-            const float sgn = (c & 1) ? -1.0f : 1.0f;   // (-1)^n, n = 512 n1 + n2
+        for (int j = 0; j < S::COLS_PER_WAVE / S::SUBA; ++j) {
+            const int cl = S::COLS_PER_WAVE * wave + S::SUBA * j + sub;   // column inside the tile
+            const int c = kColTile * ct + cl;                             // n2
+            const float sgn = (c & 1) ? -1.0f : 1.0f;                     // (-1)^n, n = N2 n1 + n2
             const float off = -(kTwo23 + 127.0f) * sgn;
-            cf x[G1::P];
+            cf x[G::P];
 #pragma unroll
-            for (int a = 0; a < G1::P; ++a) {
-                const int n1 = t + 64 * a;
+            for (int a = 0; a < G::P; ++a) {
+                const int n1 = t + T * a;
                 const uint32_t iq =
                     *reinterpret_cast<const uint16_t*>(raw + 4 * (n1 * kRowDwords + (cl >> 1)) + 2 * (cl & 1));
                 const cf v = iq_plus_2p23(iq);
                 if constexpr (WINDOW) {
-                    const float w = window[static_cast<size_t>(kN2) * n1 + c] * sgn;
+                    const float w = window[static_cast<size_t>(N2) * n1 + c] * sgn;
                     x[a] = (v - (kTwo23 + 127.0f)) * w;
                 } else {
                     x[a] = v * sgn + off;
                 }
             }
-            wave_fft512(t, x, tw, slab);
+            group_fft<G>(t, x, tw, slab);
             // inter-step twiddle W_N^{n2 k1} (n2 k1 < N: no reduction needed), then
-            // through the wave's slab into natural k1 order for a coalesced row store
+            // through the group's slab into natural k1 order for a coalesced row store
             exchange_sync<false>();
 #pragma unroll
-            for (int a = 0; a < G1::P; ++a) {
-                const int k1 = bin_of<G1>(t, a);
-                slab[G1::slot(k1)] = cmul(x[a], twN[c * k1]);
+            for (int a = 0; a < G::P; ++a) {
+                const int k1 = bin_of<G>(t, a);
+                slab[G::slot(k1)] = cmul(x[a], twN[c * k1]);
             }
             exchange_sync<false>();
-            cf* const yrow = Y + (static_cast<size_t>(f) * kN2 + c) * kN1;
+            cf* const yrow = Y + (static_cast<size_t>(f) * N2 + c) * N1;
 #pragma unroll
-            for (int a = 0; a < G1::P; ++a) yrow[t + 64 * a] = slab[G1::slot(t + 64 * a)];
+            for (int a = 0; a < G::P; ++a) yrow[t + T * a] = slab[G::slot(t + T * a)];
             exchange_sync<false>();
         }
     }
 }
 
+template <class S>
 __global__ __launch_bounds__(kWG, 4) void fourstep_rows_kernel(const cf* __restrict__ Y, int nframes,
-                                                              const cf* __restrict__ tw512,
+                                                              const cf* __restrict__ tw_sub,
                                                               double* __restrict__ partial, int first)
 {
+    using G = typename S::GB;
+    constexpr int N1 = S::N1, N2 = S::N2, T = G::T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cf* const tile = reinterpret_cast<cf*>(smem);                                   // [512][17]
-    cf* const slabs = tile + kN2 * kRowPitch;                                       // [16][576]
+    cf* const tile = reinterpret_cast<cf*>(smem);                                   // [N2][ROW_PITCH]
+    cf* const slabs = tile + N2 * S::ROW_PITCH;                                     // [16][SLAB_B]
 
     const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), t = tid & 63;
-    cf* const slab = slabs + wave * kSlab;
-    const int ktile = blockIdx.x % (kN1 / kRowTile), fg = blockIdx.x / (kN1 / kRowTile);
-    const int ngroups = gridDim.x / (kN1 / kRowTile);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int sub = lane / T, t = lane % T;
+    const int jrow = wave * S::SUBB + sub;                 // this lane group's row inside the tile
+    cf* const slab = slabs + wave * S::SLAB_B + sub * G::LDS_CPX;
+    const int ktile = blockIdx.x % S::ROW_TILES, fg = blockIdx.x / S::ROW_TILES;
+    const int ngroups = gridDim.x / S::ROW_TILES;
 
-    cf tw[G1::NPASS - 1][G1::P - 1];
-    load_twiddles<G1, 1>(t, tw512, tw);
-    double acc[G1::P];
+    cf tw[G::NPASS - 1][G::P - 1];
+    load_twiddles<G, 1>(t, tw_sub, tw);
+    double acc[G::P];
 #pragma unroll
-    for (int a = 0; a < G1::P; ++a) acc[a] = 0.0;
+    for (int a = 0; a < G::P; ++a) acc[a] = 0.0;
 
 #pragma unroll 1
     for (int f = fg; f < nframes; f += ngroups) {
-        const cf* const yf = Y + static_cast<size_t>(f) * kNBig + kRowTile * ktile;
+        const cf* const yf = Y + static_cast<size_t>(f) * S::N + S::ROW_TILE * ktile;
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < kN2 * kRowTile / kWG; ++i) {
+        for (int i = 0; i < N2 * S::ROW_TILE / kWG; ++i) {
             const int idx = i * kWG + tid;
-            const int n2 = idx / kRowTile, j = idx % kRowTile;
-            tile[n2 * kRowPitch + j] = yf[static_cast<size_t>(n2) * kN1 + j];
+            const int n2 = idx / S::ROW_TILE, j = idx % S::ROW_TILE;
+            tile[n2 * S::ROW_PITCH + j] = yf[static_cast<size_t>(n2) * N1 + j];
         }
         __syncthreads();
-        cf x[G1::P];
+        cf x[G::P];
 #pragma unroll
-        for (int a = 0; a < G1::P; ++a) x[a] = tile[(t + 64 * a) * kRowPitch + wave];
-        wave_fft512(t, x, tw, slab);
-        phase_accumulate(x, acc, G1::P);
+        for (int a = 0; a < G::P; ++a) x[a] = tile[(t + T * a) * S::ROW_PITCH + jrow];
+        group_fft<G>(t, x, tw, slab);
+        phase_accumulate(x, acc, G::P);
         exchange_sync<false>();
     }
 
-    // bins k = k1 + 512 k2: for a fixed k2 the tile's 16 rows are 16 consecutive
-    // doubles = one 128-byte line of the partial spectrum
+    // bins k = k1 + N1 k2: for a fixed k2 the tile's rows are ROW_TILE consecutive
+    // doubles = whole 128-byte lines of the partial spectrum
     __syncthreads();
-    double* const stage = reinterpret_cast<double*>(smem);                          // [512 k2][17]
+    double* const stage = reinterpret_cast<double*>(smem);                          // [N2 k2][ROW_PITCH]
 #pragma unroll
-    for (int a = 0; a < G1::P; ++a) stage[bin_of<G1>(t, a) * kRowPitch + wave] = acc[a];
+    for (int a = 0; a < G::P; ++a) stage[bin_of<G>(t, a) * S::ROW_PITCH + jrow] = acc[a];
     __syncthreads();
-    double* const out = partial + static_cast<size_t>(fg) * kNBig + kRowTile * ktile;
+    double* const out = partial + static_cast<size_t>(fg) * S::N + S::ROW_TILE * ktile;
 #pragma unroll
-    for (int i = 0; i < kN2 * kRowTile / kWG; ++i) {
+    for (int i = 0; i < N2 * S::ROW_TILE / kWG; ++i) {
         const int idx = i * kWG + tid;
-        const int k2 = idx / kRowTile, j = idx % kRowTile;
-        double* p = out + static_cast<size_t>(k2) * kN1 + j;
-        const double v = stage[k2 * kRowPitch + j];
+        const int k2 = idx / S::ROW_TILE, j = idx % S::ROW_TILE;
+        double* p = out + static_cast<size_t>(k2) * N1 + j;
+        const double v = stage[k2 * S::ROW_PITCH + j];
         *p = first ? v : (*p + v);
     }
 }
 
-template <class K>
-hipError_t set_lds(K kernel, int bytes)
+// ---------------------------------------------------------------- dispatch --
+using ColsFn = void (*)(const uint8_t*, int, const cf*, const cf*, const float*, cf*);
+using RowsFn = void (*)(const cf*, int, const cf*, double*, int);
+
+struct SplitInfo {
+    int N, N1, N2, cols_lds, rows_lds, batch, groups, row_tiles;
+    ColsFn cols[2][2];   // [window][dma]
+    RowsFn rows;
+};
+
+template <int N1, int N2>
+SplitInfo make_split()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    using S = Split<N1, N2>;
+    return SplitInfo{S::N, N1, N2, S::COLS_LDS, S::ROWS_LDS, S::BATCH, S::GROUPS, S::ROW_TILES,
+                     {{fourstep_cols_kernel<S, false, false>, fourstep_cols_kernel<S, false, true>},
+                      {fourstep_cols_kernel<S, true, false>, fourstep_cols_kernel<S, true, true>}},
+                     fourstep_rows_kernel<S>};
+}
+
+const SplitInfo kSplits[] = {
+    make_split<128, 128>(),   // 16384
+    make_split<256, 128>(),   // 32768
+    make_split<256, 256>(),   // 65536
+    make_split<512, 256>(),   // 131072
+    make_split<512, 512>(),   // 262144 (config C4)
+};
+
+const SplitInfo* find_split(int N)
+{
+    for (const SplitInfo& s : kSplits)
+        if (s.N == N) return &s;
+    return nullptr;
 }
 
 }  // namespace
 
-bool fourstep_supported(int N) { return N == kNBig; }
+bool fourstep_supported(int N) { return find_split(N) != nullptr; }
 
-size_t fourstep_scratch_bytes(int N) { return fourstep_supported(N) ? sizeof(cf) * kNBig * kFourStepBatch : 0; }
+size_t fourstep_scratch_bytes(int N)
+{
+    const SplitInfo* s = find_split(N);
+    return s ? sizeof(cf) * static_cast<size_t>(s->N) * s->batch : 0;
+}
 
-int fourstep_partial_slots(int N) { return fourstep_supported(N) ? kFrameGroups : 0; }
+int fourstep_partial_slots(int N)
+{
+    const SplitInfo* s = find_split(N);
+    return s ? s->groups : 0;
+}
+
+int fourstep_sub_lengths(int N, int* n1, int* n2)
+{
+    const SplitInfo* s = find_split(N);
+    if (!s) return 0;
+    *n1 = s->N1;
+    *n2 = s->N2;
+    return 1;
+}
 
 hipError_t fourstep_prepare(int N, int device, LaunchInfo* li)
 {
-    if (!fourstep_supported(N)) return hipErrorInvalidValue;
+    const SplitInfo* s = find_split(N);
+    if (!s) return hipErrorInvalidValue;
     hipError_t err;
-    if ((err = set_lds(fourstep_cols_kernel<false, false>, kColsLds)) != hipSuccess) return err;
-    if ((err = set_lds(fourstep_cols_kernel<false, true>, kColsLds)) != hipSuccess) return err;
-    if ((err = set_lds(fourstep_cols_kernel<true, false>, kColsLds)) != hipSuccess) return err;
-    if ((err = set_lds(fourstep_cols_kernel<true, true>, kColsLds)) != hipSuccess) return err;
-    if ((err = set_lds(fourstep_rows_kernel, kRowsLds)) != hipSuccess) return err;
+    for (int w = 0; w < 2; ++w)
+        for (int d = 0; d < 2; ++d) {
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(s->cols[w][d]),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, s->cols_lds);
+            if (err != hipSuccess) return err;
+        }
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(s->rows),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, s->rows_lds);
+    if (err != hipSuccess) return err;
     hipDeviceProp_t prop;
     if ((err = hipGetDeviceProperties(&prop, device)) != hipSuccess) return err;
     li->grid = prop.multiProcessorCount;      // one 1024-thread workgroup per CU
     li->block = kWG;
     li->fpw = 1;
-    li->lds_bytes = kRowsLds;
+    li->lds_bytes = s->rows_lds;
     return hipSuccess;
 }
 
 hipError_t launch_fourstep(int N, bool window, bool use_dma, const uint8_t* d_stream, long nframes,
-                           const cf* d_tw512, const cf* d_twN, const float* d_window, cf* d_scratch,
-                           double* d_partial, int max_grid, hipStream_t stream)
+                           const cf* d_tw_n1, const cf* d_tw_n2, const cf* d_twN, const float* d_window,
+                           cf* d_scratch, double* d_partial, int max_grid, hipStream_t stream)
 {
-    if (!fourstep_supported(N) || nframes < 1) return hipErrorInvalidValue;
-    const int rows_grid = (kN1 / kRowTile) * kFrameGroups;
+    const SplitInfo* s = find_split(N);
+    if (!s || nframes < 1) return hipErrorInvalidValue;
+    const int rows_grid = s->row_tiles * s->groups;
+    const ColsFn cols = s->cols[window ? 1 : 0][use_dma ? 1 : 0];
     bool first = true;
-    for (long done = 0; done < nframes; done += kFourStepBatch) {
-        const int nb = static_cast<int>(std::min<long>(kFourStepBatch, nframes - done));
-        const uint8_t* src = d_stream + static_cast<size_t>(done) * 2 * kNBig;
-        const int cols_grid = std::min(max_grid, nb * (kN2 / kColTile));
-        if (window) {
-            if (use_dma)
-                hipLaunchKernelGGL((fourstep_cols_kernel<true, true>), dim3(cols_grid), dim3(kWG), kColsLds,
-                                   stream, src, nb, d_tw512, d_twN, d_window, d_scratch);
-            else
-                hipLaunchKernelGGL((fourstep_cols_kernel<true, false>), dim3(cols_grid), dim3(kWG), kColsLds,
-                                   stream, src, nb, d_tw512, d_twN, d_window, d_scratch);
-        } else {
-            if (use_dma)
-                hipLaunchKernelGGL((fourstep_cols_kernel<false, true>), dim3(cols_grid), dim3(kWG), kColsLds,
-                                   stream, src, nb, d_tw512, d_twN, d_window, d_scratch);
-            else
-                hipLaunchKernelGGL((fourstep_cols_kernel<false, false>), dim3(cols_grid), dim3(kWG), kColsLds,
-                                   stream, src, nb, d_tw512, d_twN, d_window, d_scratch);
-        }
+    for (long done = 0; done < nframes; done += s->batch) {
+        const int nb = static_cast<int>(std::min<long>(s->batch, nframes - done));
+        const uint8_t* src = d_stream + static_cast<size_t>(done) * 2 * s->N;
+        const int cols_grid = std::min(max_grid, nb * (s->N2 / kColTile));
+        hipLaunchKernelGGL(cols, dim3(cols_grid), dim3(kWG), s->cols_lds, stream, src, nb, d_tw_n1, d_twN,
+                           d_window, d_scratch);
         hipError_t err = hipGetLastError();
         if (err != hipSuccess) return err;
-        hipLaunchKernelGGL(fourstep_rows_kernel, dim3(rows_grid), dim3(kWG), kRowsLds, stream, d_scratch,
-                           nb, d_tw512, d_partial, first ? 1 : 0);
+        hipLaunchKernelGGL(s->rows, dim3(rows_grid), dim3(kWG), s->rows_lds, stream, d_scratch, nb, d_tw_n2,
+                           d_partial, first ? 1 : 0);
         err = hipGetLastError();
         if (err != hipSuccess) return err;
         first = false;

@@ -47,16 +47,17 @@ hipError_t launch_bluestein(int N, const uint8_t* d_stream, long nframes, const 
                             const cf* d_g, const cf* d_bhat, double* d_partial, int grid,
                             hipStream_t stream, LaunchInfo* li);
 
-// ---- four-step path (rpf_fourstep.hip): N = 512 x 512 ------------------------
-constexpr int kFourStepBatch = 64;     // frames per K2a/K2b launch pair (128 MB of scratch)
+// ---- four-step path (rpf_fourstep.hip): N = N1 x N2, powers of two 16384..262144 --
 bool fourstep_supported(int N);
-size_t fourstep_scratch_bytes(int N);  // intermediate Y[batch][N2][N1] complex floats
+size_t fourstep_scratch_bytes(int N);  // intermediate Y[batch][N2][N1] complex floats (128 MB)
 int fourstep_partial_slots(int N);     // partial spectra written by K2b (frame groups)
+int fourstep_sub_lengths(int N, int* n1, int* n2);
 hipError_t fourstep_prepare(int N, int device, LaunchInfo* li);
 // Frames [0, nframes) -> d_partial[slots][N] (overwritten); K3 then sums the slots.
+// d_tw_n1 / d_tw_n2: master twiddle tables of the two sub-transform lengths.
 hipError_t launch_fourstep(int N, bool window, bool use_dma, const uint8_t* d_stream, long nframes,
-                           const cf* d_tw512, const cf* d_twN, const float* d_window, cf* d_scratch,
-                           double* d_partial, int max_grid, hipStream_t stream);
+                           const cf* d_tw_n1, const cf* d_tw_n2, const cf* d_twN, const float* d_window,
+                           cf* d_scratch, double* d_partial, int max_grid, hipStream_t stream);
 
 // Master twiddle table W_N^k = exp(-2 pi i k / N), k in [0,N), evaluated in
 // long double and rounded once to float.

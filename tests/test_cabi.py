@@ -33,9 +33,10 @@ def test_library_exports_every_declared_symbol():
 
 def test_supported_sizes():
     lib = rpf.load()
-    for n in (2, 6, 32, 64, 128, 256, 500, 512, 1000, 1024, 2046, 2048, 3000, 4094, 4096, 8192, 262144):
+    for n in (2, 6, 32, 64, 128, 256, 500, 512, 1000, 1024, 2046, 2048, 3000, 4094, 4096, 8192, 16384,
+              32768, 65536, 131072, 262144):
         assert lib.rpf_supported_n(n) == 1
-    for n in (0, 1, 513, 4098, 5000, 16384, 65536):
+    for n in (0, 1, 513, 4098, 5000, 16386, 524288):
         assert lib.rpf_supported_n(n) == 0
 
 

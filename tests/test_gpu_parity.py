@@ -109,22 +109,27 @@ def test_non_power_of_two_sizes_match_oracle(N, windowed, torch_dev):
     assert max_rel(host, got) < 1e-13
 
 
-def test_four_step_size_matches_oracle(torch_dev):
-    """Config C4's size (N = 262144 = 512 x 512, rpf_fourstep.hip) on noise-only
-    input, against the float32 oracle and float64 truth, windowed and not."""
-    N, R = 262144, 24
-    stream = rpf.synth.uniform_iq(44, N * R + 1000)
+@pytest.mark.parametrize("N", [16384, 32768, 65536, 131072, 262144])
+def test_four_step_sizes_match_oracle(N, torch_dev):
+    """Powers of two beyond one workgroup's LDS (rpf_fourstep.hip; 262144 is config
+    C4's size) on noise-only input, against the float32 oracle and float64 truth,
+    windowed and not, LDS-DMA and VGPR staging, device and queue paths."""
+    R = 20 if N < 262144 else 12
+    stream = rpf.synth.uniform_iq(44 + N % 97, N * R + 1000)
     for windowed in (False, True):
         w = rpf.synth.hann_window(N) + np.float32(0.25) if windowed else None
         with rpf.Datastore(rpf.Params(N=N, window=windowed, repeats=R), w) as ds:
             got, n = run_device(ds, stream, R, torch_dev)
-            got_nodma, _ = run_device(rpf.Datastore(rpf.Params(N=N, window=windowed, repeats=R), w,
-                                                    flags=rpf._lib.FLAG_NO_LDS_DMA), stream, R, torch_dev)
-        assert n == R
+            host, done = ds.accumulate(stream, R)
+        with rpf.Datastore(rpf.Params(N=N, window=windowed, repeats=R), w,
+                           flags=rpf._lib.FLAG_NO_LDS_DMA) as ds2:
+            got_nodma, _ = run_device(ds2, stream, R, torch_dev)
+        assert n == done == R
         assert np.array_equal(got, got_nodma)
+        assert max_rel(host, got) < 1e-13
         o32, _ = oracle_accumulate(N, stream, R, w, 32)
         assert max_rel(got, o32) < PARITY
-        assert max_rel(got, truth_f64(N, stream, R, w)) < VS_TRUTH * 1.5   # 18 butterfly stages instead of 12
+        assert max_rel(got, truth_f64(N, stream, R, w)) < VS_TRUTH * 1.5   # up to 18 butterfly stages
 
 
 def test_known_answers_on_device(torch_dev):
