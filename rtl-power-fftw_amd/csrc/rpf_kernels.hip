@@ -452,6 +452,9 @@ const Variant kVariants[] = {
     make_variant<4096, 16, 3, 2, false, 0, false, 2, 8, true>(14),    // no HBM staging
     make_variant<4096, 16, 3, 2, false, 0, false, 2, 6, true>(15),    // no arithmetic, no exchanges
     make_variant<4096, 16, 3, 2, false, 0, false, 2, 3, true>(16),    // no arithmetic at all
+    make_variant<4096, 16, 3, 2, false, 0, false, 2, 12, true>(17),   // butterflies + accumulate only (no exchanges, no staging)
+    make_variant<4096, 16, 3, 2, false, 0, false, 2, 13, true>(18),   // butterflies only
+    make_variant<4096, 16, 3, 2, false, 0, false, 2, 14, true>(19),   // accumulate only (+ barriers, unpack)
 };
 
 const Variant* find_variant(int N, int vid)
