@@ -409,11 +409,11 @@ struct Variant {
 // must admit (= resident workgroups per CU x WG/256).  vid = tuning variant
 // (0 = the default for this N).
 template <int N, int P, int OCC, int OCCW = OCC, bool DBUF = false, int ACCB = 0, bool PF32 = false,
-          int RAWD = 2, int ABL = 0, bool TWLDS = false, bool RAWREG = false>
+          int RAWD = 2, int ABL = 0, bool TWLDS = false, bool RAWREG = false, int WGO = 0>
 Variant make_variant(int vid)
 {
     using G = Geom<N, P>;
-    constexpr int WG = G::T >= 256 ? G::T : 256;
+    constexpr int WG = WGO ? WGO : (G::T >= 256 ? G::T : 256);   // WGO: several frames per workgroup
     constexpr int FPW = WG / G::T;
     constexpr int LDS = FPW * ((DBUF ? 2 : 1) * G::LDS_CPX * (int)sizeof(cf) + RAWD * 2 * N) +
                         (TWLDS ? twlds_entries<G>() * (int)sizeof(cf) : 0);
@@ -429,8 +429,10 @@ const Variant kVariants[] = {
     make_variant<64, 8, 4, 4, false, 0, false, 4>(0),    make_variant<128, 8, 4, 4, false, 0, false, 4>(0),
     make_variant<256, 8, 4, 4, false, 0, false, 4>(0),   make_variant<512, 8, 4, 4, false, 0, false, 2>(0),
     make_variant<1024, 16, 3, 2, false, 0, false, 2, 0, true>(0),
-    make_variant<2048, 16, 3, 2, false, 0, false, 2, 0, true>(0),
-    make_variant<4096, 16, 3, 2, false, 0, false, 2, 0, true>(0),
+    // 2048/4096: one 512-thread workgroup per CU (4 / 2 frames side by side): as fast as three
+    // 256-thread workgroups (the kernel is VALU-bound at 8 waves) and a third of the partials.
+    make_variant<2048, 16, 2, 2, false, 0, false, 2, 0, true, false, 512>(0),
+    make_variant<4096, 16, 2, 2, false, 0, false, 2, 0, true, false, 512>(0),
     make_variant<8192, 16, 2, 2, false, 0, false, 2>(0),
     // tuning variants (RPF_FLAG_VARIANT(k)); every one is exact unless it says float32
     make_variant<4096, 16, 3, 2, false, 0, false, 2>(1),              // all twiddles in registers
@@ -438,12 +440,21 @@ const Variant kVariants[] = {
     make_variant<4096, 16, 2, 2, true, 0, false, 2, 0, true>(3),      // double-buffered slab (one barrier per frame)
     make_variant<4096, 16, 3, 3, false, 8, true, 2, 0, true>(4),      // float32 batch accumulate + float32 partials
     make_variant<4096, 8, 4, 4, false, 0, false, 2>(5),               // 8 points per lane, 512 threads
+    make_variant<4096, 16, 3, 3, false, 0, false, 2, 0, true, false, 768>(8),   // one 768-thread workgroup per CU, 3 frames side by side
+    make_variant<4096, 16, 3, 2, false, 0, false, 2, 0, true>(9),               // 256 threads, 3 (windowed: 2) workgroups per CU
+    make_variant<4096, 16, 2, 2, false, 0, false, 2, 0, true>(10),              // 256 threads, 2 workgroups per CU
+    make_variant<4096, 16, 2, 2, false, 0, false, 4, 0, true, false, 512>(20),  // 512 threads, raw ring 4 deep
+    make_variant<4096, 16, 2, 2, false, 0, false, 3, 0, true, false, 512>(21),  // 512 threads, raw ring 3 deep
+    make_variant<4096, 16, 2, 2, false, 8, true, 2, 0, true, false, 512>(22),   // 512 threads, f32 batch accumulators
     make_variant<4096, 16, 3, 2, false, 0, false, 1, 0, true, true>(6),   // next frame prefetched in VGPRs, no LDS-DMA
     make_variant<4096, 16, 3, 3, false, 8, true, 1, 0, true, true>(7),    // same + float32 batch accumulate/partials
     make_variant<512, 8, 4, 4, false, 0, false, 4>(1),  make_variant<512, 8, 4, 4, false, 0, false, 8>(2),
     make_variant<512, 16, 3, 3, false, 0, false, 2>(3),
     make_variant<1024, 8, 4, 4, false, 0, false, 4>(1), make_variant<2048, 8, 4, 4, false, 0, false, 4>(1),
     make_variant<1024, 16, 3, 3, false, 0, false, 2>(2), make_variant<2048, 16, 3, 3, false, 0, false, 2>(2),
+    make_variant<1024, 16, 2, 2, false, 0, false, 2, 0, true, false, 512>(9),
+    make_variant<2048, 16, 3, 2, false, 0, false, 2, 0, true>(9),
+    make_variant<512, 8, 2, 2, false, 0, false, 2, 0, false, false, 512>(9),
     make_variant<8192, 16, 2, 2, false, 0, false, 2, 0, true>(1),
     // measurement-only ablations of the default N=4096 kernel (results are garbage)
     make_variant<4096, 16, 3, 2, false, 0, false, 2, 1, true>(11),    // no accumulate

@@ -28,11 +28,14 @@ shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, tag + "_bench.jso
 
 def means(path, full_grid_only=True):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(path)):
+    rows = list(csv.DictReader(open(path)))
+    # the C2 steps launch the full persistent grid; the small correctness check does not
+    full = max([int(r["Grid_Size"]) for r in rows if "fft_accum_kernel" in r["Kernel_Name"]] or [0])
+    for r in rows:
         name = r["Kernel_Name"]
         if "fft_accum_kernel" in name:
             k = "K1_fft_accum"
-            if full_grid_only and int(r["Grid_Size"]) < 768 * 256:
+            if full_grid_only and int(r["Grid_Size"]) < full:
                 continue
         elif "reduce_kernel" in name:
             k = "K3_reduce"
