@@ -84,6 +84,8 @@ struct rpf_engine {
     rpf::cf* d_twiddles = nullptr;
     bool fourstep = false;                // N handled by rpf_fourstep.hip
     bool bluestein = false;               // N handled by the Bluestein kernel (chirp tables below)
+    bool bigblu = false;                  // N handled by the large (four-step) Bluestein path
+    int blu_M = 0;                        // bigblu: convolution length (partial spectra have M entries)
     rpf::cf* d_chirp = nullptr;           // g[n], N entries
     rpf::cf* d_bhat = nullptr;            // frequency-domain chirp, M entries
     rpf::cf* d_tw_sub = nullptr;          // four-step: twiddles of the N1-point column transforms
@@ -134,6 +136,14 @@ int launch_transform(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, hi
         *nslots = rpf::fourstep_partial_slots(e->N);
         return RPF_OK;
     }
+    if (e->bigblu) {
+        const bool dma = e->use_dma && (addr % 4) == 0;
+        HIP_TRY(e, rpf::launch_bigblu(e->N, dma, d_frames, nframes, e->d_tw_sub, e->d_tw_sub2, e->d_twiddles,
+                                      e->d_chirp, e->d_bhat, e->d_scratch, e->d_partial, e->plan.grid, stream));
+        e->last = e->plan;
+        *nslots = rpf::bigblu_partial_slots(e->N);
+        return RPF_OK;
+    }
     const int64_t wanted = (nframes + e->plan.fpw - 1) / e->plan.fpw;
     const int grid = static_cast<int>(std::min<int64_t>(e->plan.grid, wanted));
     if (e->bluestein) {
@@ -159,7 +169,7 @@ int launch_frames(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, doubl
     if (rc != RPF_OK) return rc;
     e->last_slots = nslots;
     HIP_TRY(e, rpf::launch_reduce(e->d_partial, nslots, e->N, d_out, accumulate, stream,
-                                  e->plan.partial_f32));
+                                  e->plan.partial_f32, e->bigblu ? static_cast<size_t>(e->blu_M) : 0));
     return RPF_OK;
 }
 
@@ -294,7 +304,8 @@ int rpf_abi_version(void) { return RPF_ABI_VERSION; }
 
 int rpf_supported_n(int N)
 {
-    return (rpf::kernel_supported(N) || rpf::fourstep_supported(N) || rpf::bluestein_supported(N)) ? 1 : 0;
+    return (rpf::kernel_supported(N) || rpf::fourstep_supported(N) || rpf::bluestein_supported(N) ||
+            rpf::bigblu_supported(N)) ? 1 : 0;
 }
 
 const char* rpf_last_global_error(void) { return g_last_error.c_str(); }
@@ -311,10 +322,11 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
     const int variant = static_cast<int>((cfg->flags >> 8) & 0xffu);
     const bool fourstep = rpf::fourstep_supported(cfg->N) && variant == 0;
     const bool bluestein = rpf::bluestein_supported(cfg->N) && variant == 0;
-    if (!fourstep && !bluestein && !rpf::kernel_supported(cfg->N, variant))
+    const bool bigblu = rpf::bigblu_supported(cfg->N) && variant == 0;
+    if (!fourstep && !bluestein && !bigblu && !rpf::kernel_supported(cfg->N, variant))
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT,
                     "No gfx950 kernel for " + std::to_string(cfg->N) +
-                        " bins in this build (supported: every even N up to 4096 and the powers of two up to 262144).");
+                        " bins in this build (supported: every even N up to 131072 and the powers of two up to 262144).");
     if (cfg->n_buffers < 1)
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT, "Argument to 'buffers' must be a positive number.");
     if (cfg->buffer_capacity < 2 || (cfg->buffer_capacity % 2) != 0)
@@ -341,6 +353,7 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
     e->variant = variant;
     e->fourstep = fourstep;
     e->bluestein = bluestein;
+    e->bigblu = bigblu;
     e->queue_histogram.assign(e->n_buffers + 1, 0);
     e->pwr.assign(e->N, 0.0);
 
@@ -364,23 +377,39 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
 
     // "plan": twiddle table on the device (where fftwf_plan_dft_1d stands, datastore.cxx:32)
     std::vector<rpf::cf> tw;
-    rpf::make_twiddles(e->bluestein ? rpf::bluestein_length(e->N) : e->N, tw);
+    int blu_m1 = 0, blu_m2 = 0;
+    if (e->bigblu) rpf::bigblu_lengths(e->N, &e->blu_M, &blu_m1, &blu_m2);
+    rpf::make_twiddles(e->bluestein ? rpf::bluestein_length(e->N) : e->bigblu ? e->blu_M : e->N, tw);
     CREATE_TRY(hipMalloc(&e->d_twiddles, sizeof(rpf::cf) * tw.size()));
     CREATE_TRY(hipMemcpy(e->d_twiddles, tw.data(), sizeof(rpf::cf) * tw.size(), hipMemcpyHostToDevice));
     if (e->has_window) {
         CREATE_TRY(hipMalloc(&e->d_window, sizeof(float) * e->N));
         CREATE_TRY(hipMemcpy(e->d_window, cfg->window, sizeof(float) * e->N, hipMemcpyHostToDevice));
     }
-    size_t partial_slots = 0;
-    if (e->bluestein) {
+    size_t partial_slots = 0, partial_len = e->N;
+    if (e->bluestein || e->bigblu) {
         std::vector<float> g, bhat;
         rpf::make_bluestein_tables(e->N, cfg->window, g, bhat);
         CREATE_TRY(hipMalloc(&e->d_chirp, sizeof(float) * g.size()));
         CREATE_TRY(hipMemcpy(e->d_chirp, g.data(), sizeof(float) * g.size(), hipMemcpyHostToDevice));
         CREATE_TRY(hipMalloc(&e->d_bhat, sizeof(float) * bhat.size()));
         CREATE_TRY(hipMemcpy(e->d_bhat, bhat.data(), sizeof(float) * bhat.size(), hipMemcpyHostToDevice));
+    }
+    if (e->bluestein) {
         CREATE_TRY(rpf::plan_bluestein(e->N, e->device, &e->plan));
         partial_slots = e->plan.grid;
+    } else if (e->bigblu) {
+        CREATE_TRY(rpf::bigblu_prepare(e->N, e->device, &e->plan));
+        std::vector<rpf::cf> tws;
+        rpf::make_twiddles(blu_m1, tws);
+        CREATE_TRY(hipMalloc(&e->d_tw_sub, sizeof(rpf::cf) * tws.size()));
+        CREATE_TRY(hipMemcpy(e->d_tw_sub, tws.data(), sizeof(rpf::cf) * tws.size(), hipMemcpyHostToDevice));
+        rpf::make_twiddles(blu_m2, tws);
+        CREATE_TRY(hipMalloc(&e->d_tw_sub2, sizeof(rpf::cf) * tws.size()));
+        CREATE_TRY(hipMemcpy(e->d_tw_sub2, tws.data(), sizeof(rpf::cf) * tws.size(), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc(&e->d_scratch, rpf::bigblu_scratch_bytes(e->N)));
+        partial_slots = rpf::bigblu_partial_slots(e->N);
+        partial_len = e->blu_M;
     } else if (e->fourstep) {
         CREATE_TRY(rpf::fourstep_prepare(e->N, e->device, &e->plan));
         int n1 = 0, n2 = 0;
@@ -401,7 +430,7 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         e->plan.grid = std::min(e->plan.grid, tmp.grid);
         partial_slots = e->plan.grid;
     }
-    CREATE_TRY(hipMalloc(&e->d_partial, sizeof(double) * e->N * partial_slots));
+    CREATE_TRY(hipMalloc(&e->d_partial, sizeof(double) * partial_len * partial_slots));
     CREATE_TRY(hipMalloc(&e->d_pwr, sizeof(double) * e->N));
     CREATE_TRY(hipMemset(e->d_pwr, 0, sizeof(double) * e->N));
 

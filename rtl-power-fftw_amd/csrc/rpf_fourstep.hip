@@ -71,13 +71,17 @@ __device__ __forceinline__ void group_fft(int t, cf* x, const cf (&tw)[G::NPASS 
     phase_last<G>(x);
 }
 
-template <class S, bool WINDOW, bool DMA>
+// BLU: first step of the large Bluestein path (see bluestein_mid_kernel): the
+// frame has n_true < S::N samples, a[n] = (v[n] - 127) g[n] zero-padded to S::N
+// (g carries (-1)^n, the window and the chirp), frames are n_true samples apart.
+template <class S, bool WINDOW, bool DMA, bool BLU = false>
 __global__ __launch_bounds__(kWG, 4) void fourstep_cols_kernel(const uint8_t* __restrict__ stream,
                                                               int nframes,
                                                               const cf* __restrict__ tw_sub,
                                                               const cf* __restrict__ twN,
                                                               const float* __restrict__ window,
-                                                              cf* __restrict__ Y)
+                                                              cf* __restrict__ Y, int n_true,
+                                                              const cf* __restrict__ g)
 {
     using G = typename S::GA;
     constexpr int N1 = S::N1, N2 = S::N2, T = G::T;
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_cols_kernel(const uint8_t* __
 #pragma unroll 1
     for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
         const int f = task / TILES, ct = task % TILES;
-        const uint8_t* const frame = stream + static_cast<size_t>(f) * (2 * S::N);
+        const uint8_t* const frame = stream + static_cast<size_t>(f) * (2 * (BLU ? n_true : S::N));
 
         __syncthreads();   // the previous tile has been consumed by every wave
         // stage the [N1 rows][128 B] raw tile: LDS dword L <- row L/33, dword L%33
@@ -106,7 +110,8 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_cols_kernel(const uint8_t* __
         for (int i = 0; i < (N1 * kRowDwords + kWG - 1) / kWG; ++i) {
             const int L = i * kWG + tid;
             const int r = L / kRowDwords, d = L % kRowDwords;
-            if (L < N1 * kRowDwords && d < 32) {
+            // BLU: sample pairs past the end of the frame are never read (they are zeros)
+            if (L < N1 * kRowDwords && d < 32 && (!BLU || N2 * r + kColTile * ct + 2 * d < n_true)) {
                 const uint8_t* src = frame + 2 * (static_cast<size_t>(N2) * r + kColTile * ct) + 4 * d;
                 if constexpr (DMA) {
                     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(raw + 4 * (i * kWG + wave * 64)),
@@ -134,7 +139,11 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_cols_kernel(const uint8_t* __
                 const uint32_t iq =
                     *reinterpret_cast<const uint16_t*>(raw + 4 * (n1 * kRowDwords + (cl >> 1)) + 2 * (cl & 1));
                 const cf v = iq_plus_2p23(iq);
-                if constexpr (WINDOW) {
+                if constexpr (BLU) {
+                    const int n = N2 * n1 + c;
+                    x[a] = cf{0.0f, 0.0f};
+                    if (n < n_true) x[a] = cmul(v - (kTwo23 + 127.0f), g[n]);
+                } else if constexpr (WINDOW) {
                     const float w = window[static_cast<size_t>(N2) * n1 + c] * sgn;
                     x[a] = (v - (kTwo23 + 127.0f)) * w;
                 } else {
@@ -221,8 +230,85 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_rows_kernel(const cf* __restr
     }
 }
 
+
+// Large Bluestein path: even N in (4096, 131072] that is not a power of two,
+// M = M1 x M2 = 2^ceil(log2(2N-1)) (bluestein_tables.h has the identity):
+//   K2a (BLU)  a = (v - 127) g zero-padded to M; columns of FFT_M #1 -> Y[f][n2][k1]
+//   this kernel, per row k1: A[k1 + M1 k2] = row transform of Y (FFT_M #1 done);
+//        z = conj(A * bhat); the second FFT_M reads z[M1 m1 + m2] with (m1, m2) =
+//        (k2, k1), so its column transform (over m1 = k2, M2 points) is over the
+//        very values this lane group holds: through the slab into natural order,
+//        transform again, times W_M^{k1 q1}, coalesced store of Y2[f][k1][q1];
+//   K2b on the transposed split <M2, M1>: rows of FFT_M #2 over k1, |c[q1 + M2 q2]|^2
+//        accumulated; bins >= N of the M convolution outputs are ignored by K3.
+template <class S>
+__global__ __launch_bounds__(kWG, 4) void bluestein_mid_kernel(const cf* __restrict__ Y, int nframes,
+                                                              const cf* __restrict__ tw_sub,
+                                                              const cf* __restrict__ bhat,
+                                                              const cf* __restrict__ twM,
+                                                              cf* __restrict__ Y2)
+{
+    using G = typename S::GB;
+    constexpr int N1 = S::N1, N2 = S::N2, T = G::T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* const tile = reinterpret_cast<cf*>(smem);                                   // [N2][ROW_PITCH]
+    cf* const slabs = tile + N2 * S::ROW_PITCH;                                     // [16][SLAB_B]
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int sub = lane / T, t = lane % T;
+    const int jrow = wave * S::SUBB + sub;
+    cf* const slab = slabs + wave * S::SLAB_B + sub * G::LDS_CPX;
+
+    cf tw[G::NPASS - 1][G::P - 1];
+    load_twiddles<G, 1>(t, tw_sub, tw);
+
+    const int ntasks = nframes * S::ROW_TILES;
+#pragma unroll 1
+    for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        const int f = task / S::ROW_TILES, ktile = task % S::ROW_TILES;
+        const cf* const yf = Y + static_cast<size_t>(f) * S::N + S::ROW_TILE * ktile;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < N2 * S::ROW_TILE / kWG; ++i) {
+            const int idx = i * kWG + tid;
+            const int n2 = idx / S::ROW_TILE, j = idx % S::ROW_TILE;
+            tile[n2 * S::ROW_PITCH + j] = yf[static_cast<size_t>(n2) * N1 + j];
+        }
+        __syncthreads();
+        const int k1 = S::ROW_TILE * ktile + jrow;
+        cf x[G::P];
+#pragma unroll
+        for (int a = 0; a < G::P; ++a) x[a] = tile[(t + T * a) * S::ROW_PITCH + jrow];
+        group_fft<G>(t, x, tw, slab);
+        exchange_sync<false>();
+#pragma unroll
+        for (int a = 0; a < G::P; ++a) {
+            const int k2 = bin_of<G>(t, a);
+            cf z = cmul(x[a], bhat[k1 + N1 * k2]);
+            z.y = -z.y;
+            slab[G::slot(k2)] = z;
+        }
+        exchange_sync<false>();
+        phase_fetch<G, 1>(t, x, slab);       // natural order; pass 1 rewrites exactly these slots
+        group_fft<G>(t, x, tw, slab);
+        exchange_sync<false>();
+#pragma unroll
+        for (int a = 0; a < G::P; ++a) {
+            const int q1 = bin_of<G>(t, a);
+            slab[G::slot(q1)] = cmul(x[a], twM[k1 * q1]);    // k1 q1 < M: no reduction needed
+        }
+        exchange_sync<false>();
+        cf* const row = Y2 + (static_cast<size_t>(f) * N1 + k1) * N2;
+#pragma unroll
+        for (int a = 0; a < G::P; ++a) row[t + T * a] = slab[G::slot(t + T * a)];
+        exchange_sync<false>();
+    }
+}
+
 // ---------------------------------------------------------------- dispatch --
-using ColsFn = void (*)(const uint8_t*, int, const cf*, const cf*, const float*, cf*);
+using ColsFn = void (*)(const uint8_t*, int, const cf*, const cf*, const float*, cf*, int, const cf*);
+using MidFn = void (*)(const cf*, int, const cf*, const cf*, const cf*, cf*);
 using RowsFn = void (*)(const cf*, int, const cf*, double*, int);
 
 struct SplitInfo {
@@ -253,6 +339,40 @@ const SplitInfo* find_split(int N)
 {
     for (const SplitInfo& s : kSplits)
         if (s.N == N) return &s;
+    return nullptr;
+}
+
+// Large Bluestein: the three kernels for M = M1 x M2.
+struct BluSplitInfo {
+    int M, M1, M2, cols_lds, mid_lds, rows_lds, batch, groups, row_tiles, mid_tiles;
+    ColsFn cols[2];   // [dma]
+    MidFn mid;
+    RowsFn rows;      // on the transposed split
+};
+
+template <int M1, int M2>
+BluSplitInfo make_blu_split()
+{
+    using S = Split<M1, M2>;
+    using SR = Split<M2, M1>;
+    return BluSplitInfo{S::N, M1, M2, S::COLS_LDS, S::ROWS_LDS, SR::ROWS_LDS, S::BATCH, SR::GROUPS,
+                        SR::ROW_TILES, S::ROW_TILES,
+                        {fourstep_cols_kernel<S, false, false, true>, fourstep_cols_kernel<S, false, true, true>},
+                        bluestein_mid_kernel<S>, fourstep_rows_kernel<SR>};
+}
+
+const BluSplitInfo kBluSplits[] = {
+    make_blu_split<128, 128>(), make_blu_split<256, 128>(), make_blu_split<256, 256>(),
+    make_blu_split<512, 256>(), make_blu_split<512, 512>(),
+};
+
+const BluSplitInfo* find_blu_split(int N)
+{
+    if (N <= 4096 || (N & 1) || (N & (N - 1)) == 0) return nullptr;
+    int M = 16384;
+    while (M < 2 * N - 1) M *= 2;
+    for (const BluSplitInfo& s : kBluSplits)
+        if (s.M == M) return &s;
     return nullptr;
 }
 
@@ -318,13 +438,93 @@ hipError_t launch_fourstep(int N, bool window, bool use_dma, const uint8_t* d_st
         const uint8_t* src = d_stream + static_cast<size_t>(done) * 2 * s->N;
         const int cols_grid = std::min(max_grid, nb * (s->N2 / kColTile));
         hipLaunchKernelGGL(cols, dim3(cols_grid), dim3(kWG), s->cols_lds, stream, src, nb, d_tw_n1, d_twN,
-                           d_window, d_scratch);
+                           d_window, d_scratch, 0, static_cast<const cf*>(nullptr));
         hipError_t err = hipGetLastError();
         if (err != hipSuccess) return err;
         hipLaunchKernelGGL(s->rows, dim3(rows_grid), dim3(kWG), s->rows_lds, stream, d_scratch, nb, d_tw_n2,
                            d_partial, first ? 1 : 0);
         err = hipGetLastError();
         if (err != hipSuccess) return err;
+        first = false;
+    }
+    return hipSuccess;
+}
+
+// ---- large Bluestein path --------------------------------------------------
+bool bigblu_supported(int N) { return find_blu_split(N) != nullptr; }
+
+int bigblu_lengths(int N, int* M, int* m1, int* m2)
+{
+    const BluSplitInfo* s = find_blu_split(N);
+    if (!s) return 0;
+    *M = s->M;
+    *m1 = s->M1;
+    *m2 = s->M2;
+    return 1;
+}
+
+size_t bigblu_scratch_bytes(int N)      // Y and Y2, one after the other
+{
+    const BluSplitInfo* s = find_blu_split(N);
+    return s ? 2 * sizeof(cf) * static_cast<size_t>(s->M) * s->batch : 0;
+}
+
+int bigblu_partial_slots(int N)
+{
+    const BluSplitInfo* s = find_blu_split(N);
+    return s ? s->groups : 0;
+}
+
+hipError_t bigblu_prepare(int N, int device, LaunchInfo* li)
+{
+    const BluSplitInfo* s = find_blu_split(N);
+    if (!s) return hipErrorInvalidValue;
+    hipError_t err;
+    for (int d = 0; d < 2; ++d) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(s->cols[d]),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, s->cols_lds);
+        if (err != hipSuccess) return err;
+    }
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(s->mid), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              s->mid_lds);
+    if (err != hipSuccess) return err;
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(s->rows), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              s->rows_lds);
+    if (err != hipSuccess) return err;
+    hipDeviceProp_t prop;
+    if ((err = hipGetDeviceProperties(&prop, device)) != hipSuccess) return err;
+    li->grid = prop.multiProcessorCount;
+    li->block = kWG;
+    li->fpw = 1;
+    li->lds_bytes = s->cols_lds;
+    return hipSuccess;
+}
+
+hipError_t launch_bigblu(int N, bool use_dma, const uint8_t* d_stream, long nframes, const cf* d_tw_m1,
+                         const cf* d_tw_m2, const cf* d_twM, const cf* d_g, const cf* d_bhat, cf* d_scratch,
+                         double* d_partial, int max_grid, hipStream_t stream)
+{
+    const BluSplitInfo* s = find_blu_split(N);
+    if (!s || nframes < 1) return hipErrorInvalidValue;
+    cf* const Y = d_scratch;
+    cf* const Y2 = d_scratch + static_cast<size_t>(s->M) * s->batch;
+    const int rows_grid = s->row_tiles * s->groups;
+    bool first = true;
+    for (long done = 0; done < nframes; done += s->batch) {
+        const int nb = static_cast<int>(std::min<long>(s->batch, nframes - done));
+        const uint8_t* src = d_stream + static_cast<size_t>(done) * 2 * N;
+        const int cols_grid = std::min(max_grid, nb * (s->M2 / kColTile));
+        hipLaunchKernelGGL(s->cols[use_dma ? 1 : 0], dim3(cols_grid), dim3(kWG), s->cols_lds, stream, src, nb,
+                           d_tw_m1, d_twM, static_cast<const float*>(nullptr), Y, N, d_g);
+        hipError_t err = hipGetLastError();
+        if (err != hipSuccess) return err;
+        const int mid_grid = std::min(max_grid, nb * s->mid_tiles);
+        hipLaunchKernelGGL(s->mid, dim3(mid_grid), dim3(kWG), s->mid_lds, stream, Y, nb, d_tw_m2, d_bhat, d_twM, Y2);
+        if ((err = hipGetLastError()) != hipSuccess) return err;
+        // second transform's rows: over k1 (M1 points), tw table of length M1
+        hipLaunchKernelGGL(s->rows, dim3(rows_grid), dim3(kWG), s->rows_lds, stream, Y2, nb, d_tw_m1, d_partial,
+                           first ? 1 : 0);
+        if ((err = hipGetLastError()) != hipSuccess) return err;
         first = false;
     }
     return hipSuccess;

@@ -36,8 +36,9 @@ hipError_t launch_fft_accum(int N, int vid, bool window, bool use_dma, const uin
 
 // d_out[bin] = (accumulate ? d_out[bin] : 0) + sum_{s < nslots} d_partial[s*N + bin],
 // summed in slot order (deterministic).
+// slot_stride = distance between partial spectra in elements (0: N).
 hipError_t launch_reduce(const double* d_partial, int nslots, int N, double* d_out,
-                         bool accumulate, hipStream_t stream, bool partial_f32 = false);
+                         bool accumulate, hipStream_t stream, bool partial_f32 = false, size_t slot_stride = 0);
 
 // ---- Bluestein path (KB in rpf_kernels.hip): any other even N <= 4096 ----------
 bool bluestein_supported(int N);
@@ -58,6 +59,17 @@ hipError_t fourstep_prepare(int N, int device, LaunchInfo* li);
 hipError_t launch_fourstep(int N, bool window, bool use_dma, const uint8_t* d_stream, long nframes,
                            const cf* d_tw_n1, const cf* d_tw_n2, const cf* d_twN, const float* d_window,
                            cf* d_scratch, double* d_partial, int max_grid, hipStream_t stream);
+
+// ---- large Bluestein path (rpf_fourstep.hip): even N in (4096, 131072], not a power of two --
+bool bigblu_supported(int N);
+int bigblu_lengths(int N, int* M, int* m1, int* m2);   // M = m1 * m2 = 2^ceil(log2(2N-1))
+size_t bigblu_scratch_bytes(int N);    // two intermediates of 128 MB
+int bigblu_partial_slots(int N);       // partial spectra of M (not N) doubles each
+hipError_t bigblu_prepare(int N, int device, LaunchInfo* li);
+// d_tw_m1 / d_tw_m2 / d_twM: master twiddles of lengths m1, m2, M; d_g (N) / d_bhat (M): bluestein_tables.h
+hipError_t launch_bigblu(int N, bool use_dma, const uint8_t* d_stream, long nframes, const cf* d_tw_m1,
+                         const cf* d_tw_m2, const cf* d_twM, const cf* d_g, const cf* d_bhat, cf* d_scratch,
+                         double* d_partial, int max_grid, hipStream_t stream);
 
 // Master twiddle table W_N^k = exp(-2 pi i k / N), k in [0,N), evaluated in
 // long double and rounded once to float.

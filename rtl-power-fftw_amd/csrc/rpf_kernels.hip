@@ -367,7 +367,7 @@ constexpr int RED_BINS = 16, RED_GROUPS = 16, RED_UNROLL = 8;
 template <typename PT>
 __global__ __launch_bounds__(RED_BINS* RED_GROUPS) void reduce_kernel(
     const PT* __restrict__ partial, int nslots, int N, double* __restrict__ out,
-    int accumulate)
+    int accumulate, size_t stride)
 {
     __shared__ double red[RED_GROUPS][RED_BINS + 1];
     const int b = threadIdx.x % RED_BINS, g = threadIdx.x / RED_BINS;
@@ -380,11 +380,11 @@ __global__ __launch_bounds__(RED_BINS* RED_GROUPS) void reduce_kernel(
             PT v[RED_UNROLL];
 #pragma unroll
             for (int u = 0; u < RED_UNROLL; ++u)
-                v[u] = p[static_cast<size_t>(sl + u * RED_GROUPS) * N];
+                v[u] = p[static_cast<size_t>(sl + u * RED_GROUPS) * stride];
 #pragma unroll
             for (int u = 0; u < RED_UNROLL; ++u) s += v[u];
         }
-        for (; sl < nslots; sl += RED_GROUPS) s += p[static_cast<size_t>(sl) * N];
+        for (; sl < nslots; sl += RED_GROUPS) s += p[static_cast<size_t>(sl) * stride];
     }
     red[g][b] = s;
     __syncthreads();
@@ -610,15 +610,16 @@ hipError_t launch_bluestein(int N, const uint8_t* d_stream, long nframes, const 
 }
 
 hipError_t launch_reduce(const double* d_partial, int nslots, int N, double* d_out,
-                         bool accumulate, hipStream_t stream, bool partial_f32)
+                         bool accumulate, hipStream_t stream, bool partial_f32, size_t slot_stride)
 {
     const int blocks = (N + RED_BINS - 1) / RED_BINS;
+    const size_t stride = slot_stride ? slot_stride : static_cast<size_t>(N);
     if (partial_f32)
         hipLaunchKernelGGL(reduce_kernel<float>, dim3(blocks), dim3(RED_BINS * RED_GROUPS), 0, stream,
-                           reinterpret_cast<const float*>(d_partial), nslots, N, d_out, accumulate ? 1 : 0);
+                           reinterpret_cast<const float*>(d_partial), nslots, N, d_out, accumulate ? 1 : 0, stride);
     else
         hipLaunchKernelGGL(reduce_kernel<double>, dim3(blocks), dim3(RED_BINS * RED_GROUPS), 0, stream,
-                           d_partial, nslots, N, d_out, accumulate ? 1 : 0);
+                           d_partial, nslots, N, d_out, accumulate ? 1 : 0, stride);
     return hipGetLastError();
 }
 

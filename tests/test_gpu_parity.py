@@ -132,6 +132,31 @@ def test_four_step_sizes_match_oracle(N, torch_dev):
         assert max_rel(got, truth_f64(N, stream, R, w)) < VS_TRUTH * 1.5   # up to 18 butterfly stages
 
 
+@pytest.mark.parametrize("N", [4098, 5000, 10000, 16386, 20000, 50000, 100000, 131070])
+def test_large_non_power_of_two_sizes_match_oracle(N, torch_dev):
+    """Even N in (4096, 131072] that is not a power of two: Bluestein through the
+    four-step kernels (rpf_fourstep.hip, M = 2^ceil(log2(2N-1)) up to 262144);
+    two float32 transforms of length M per frame, so the distance to float64
+    truth is about twice the four-step one."""
+    R = 9
+    stream = rpf.synth.uniform_iq(321 + N % 89, N * R + N // 2 + 2)
+    for windowed in (False, True):
+        w = rpf.synth.hann_window(N) + np.float32(0.25) if windowed else None
+        with rpf.Datastore(rpf.Params(N=N, window=windowed, repeats=R, buf_length=1 << 20), w) as ds:
+            got, n = run_device(ds, stream, R, torch_dev)
+            host, done = ds.accumulate(stream, R)          # 1 MB buffers: frames straddle them
+        with rpf.Datastore(rpf.Params(N=N, window=windowed, repeats=R), w,
+                           flags=rpf._lib.FLAG_NO_LDS_DMA) as ds2:
+            got_nodma, _ = run_device(ds2, stream, R, torch_dev)
+        assert n == done == R
+        assert np.array_equal(got, got_nodma)
+        assert max_rel(host, got) < 1e-13
+        truth = truth_f64(N, stream, R, w)
+        assert max_err_over_mean(got, truth) < PARITY
+        o32, _ = oracle_accumulate(N, stream, R, w, 32)
+        assert max_err_over_mean(got, o32) < PARITY
+
+
 def test_known_answers_on_device(torch_dev):
     N, R = 4096, 1000
     with rpf.Datastore(rpf.Params(N=N, repeats=R)) as ds:
