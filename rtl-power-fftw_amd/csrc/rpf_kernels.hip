@@ -203,11 +203,12 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
             // the slot has been consumed: refill it with the frame RAWD iterations ahead
             if constexpr (!(ABL & 8))
                 stage_raw<G, DMA>(stream, fb + RAWD * stride, nframes, ring_slot, wave, lane);
+            RPF_STAMP(clk, 3);                   // DMA issue
         }
 
         // single slab: every wave must be done with the previous frame's slab
         if constexpr (!DBUF) exchange_sync<BLOCK_SYNC>();
-        RPF_STAMP(clk, 2);                       // DMA issue + top-of-frame barrier
+        RPF_STAMP(clk, 2);                       // top-of-frame barrier
         middle_passes<G, 1, ABL, TWLDS>(t, x, tw, slab, clk, twtable);   // stamps 4J..4J+3
         if constexpr (!(ABL & 4)) phase_fetch<G, NPASS>(t, x, slab);
         asm volatile("" : "+v"(x[0]));

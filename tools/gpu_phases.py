@@ -27,7 +27,7 @@ torch.cuda.synchronize()
 dbg(out, ctypes.byref(waves), 1)
 info = ds.launch_info()
 frames_per_wave = R * K / (waves.value / (info["block"] // 64) * info["frames_per_wg"] / K) / K if waves.value else 0
-names = {0: "wait staged bytes", 1: "unpack", 2: "DMA issue + top barrier", 4: "p1: (fetch)", 5: "p1: butterfly+tw", 6: "p1: store",
+names = {0: "wait staged bytes", 1: "unpack", 2: "top barrier", 3: "DMA issue", 4: "p1: (fetch)", 5: "p1: butterfly+tw", 6: "p1: store",
          7: "p1: sync", 8: "p2: fetch", 9: "p2: butterfly+tw", 10: "p2: store", 11: "p2: sync", 12: "last fetch",
          13: "last butterfly", 14: "accumulate"}
 tot = sum(out)
