@@ -91,6 +91,7 @@ struct rpf_engine {
     rpf::cf* d_tw_sub = nullptr;          // four-step: twiddles of the N1-point column transforms
     rpf::cf* d_tw_sub2 = nullptr;         // four-step: twiddles of the N2-point row transforms
     rpf::cf* d_scratch = nullptr;         // four-step: intermediate Y
+    rpf::cf* d_step2 = nullptr;           // large Bluestein: second transform's inter-step twiddles
     float* d_window = nullptr;
     double* d_partial = nullptr;
     double* d_pwr = nullptr;
@@ -139,7 +140,8 @@ int launch_transform(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, hi
     if (e->bigblu) {
         const bool dma = e->use_dma && (addr % 4) == 0;
         HIP_TRY(e, rpf::launch_bigblu(e->N, dma, d_frames, nframes, e->d_tw_sub, e->d_tw_sub2, e->d_twiddles,
-                                      e->d_chirp, e->d_bhat, e->d_scratch, e->d_partial, e->plan.grid, stream));
+                                      e->d_step2, e->d_chirp, e->d_bhat, e->d_scratch, e->d_partial,
+                                      e->plan.grid, stream));
         e->last = e->plan;
         *nslots = rpf::bigblu_partial_slots(e->N);
         return RPF_OK;
@@ -280,6 +282,7 @@ void release_device(rpf_engine* e)
     if (e->d_tw_sub) (void)hipFree(e->d_tw_sub);
     if (e->d_tw_sub2) (void)hipFree(e->d_tw_sub2);
     if (e->d_scratch) (void)hipFree(e->d_scratch);
+    if (e->d_step2) (void)hipFree(e->d_step2);
     if (e->d_chirp) (void)hipFree(e->d_chirp);
     if (e->d_bhat) (void)hipFree(e->d_bhat);
     if (e->d_window) (void)hipFree(e->d_window);
@@ -387,8 +390,9 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         CREATE_TRY(hipMemcpy(e->d_window, cfg->window, sizeof(float) * e->N, hipMemcpyHostToDevice));
     }
     size_t partial_slots = 0, partial_len = e->N;
+    std::vector<float> blu_g, blu_bhat;
     if (e->bluestein || e->bigblu) {
-        std::vector<float> g, bhat;
+        std::vector<float>&g = blu_g, &bhat = blu_bhat;
         rpf::make_bluestein_tables(e->N, cfg->window, g, bhat);
         CREATE_TRY(hipMalloc(&e->d_chirp, sizeof(float) * g.size()));
         CREATE_TRY(hipMemcpy(e->d_chirp, g.data(), sizeof(float) * g.size(), hipMemcpyHostToDevice));
@@ -410,6 +414,18 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         CREATE_TRY(hipMalloc(&e->d_scratch, rpf::bigblu_scratch_bytes(e->N)));
         partial_slots = rpf::bigblu_partial_slots(e->N);
         partial_len = e->blu_M;
+        // the kernels read chirp, kernel spectrum and inter-step twiddles in their own lane order
+        std::vector<rpf::cf> g_t, bhat_t, step_tw, step_tw2;
+        rpf::bigblu_tables(e->N, reinterpret_cast<const rpf::cf*>(blu_g.data()),
+                           reinterpret_cast<const rpf::cf*>(blu_bhat.data()), g_t, bhat_t, step_tw, step_tw2);
+        (void)hipFree(e->d_chirp);
+        e->d_chirp = nullptr;
+        CREATE_TRY(hipMalloc(&e->d_chirp, sizeof(rpf::cf) * g_t.size()));
+        CREATE_TRY(hipMemcpy(e->d_chirp, g_t.data(), sizeof(rpf::cf) * g_t.size(), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMemcpy(e->d_bhat, bhat_t.data(), sizeof(rpf::cf) * bhat_t.size(), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMemcpy(e->d_twiddles, step_tw.data(), sizeof(rpf::cf) * step_tw.size(), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc(&e->d_step2, sizeof(rpf::cf) * step_tw2.size()));
+        CREATE_TRY(hipMemcpy(e->d_step2, step_tw2.data(), sizeof(rpf::cf) * step_tw2.size(), hipMemcpyHostToDevice));
     } else if (e->fourstep) {
         CREATE_TRY(rpf::fourstep_prepare(e->N, e->device, &e->plan));
         int n1 = 0, n2 = 0;
@@ -423,6 +439,13 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         CREATE_TRY(hipMemcpy(e->d_tw_sub2, tws.data(), sizeof(rpf::cf) * tws.size(), hipMemcpyHostToDevice));
         CREATE_TRY(hipMalloc(&e->d_scratch, rpf::fourstep_scratch_bytes(e->N)));
         partial_slots = rpf::fourstep_partial_slots(e->N);
+        // K2a reads the inter-step twiddles and the window in its own lane order
+        std::vector<rpf::cf> step_tw;
+        std::vector<float> window_t;
+        rpf::fourstep_tables(e->N, cfg->window, step_tw, window_t);
+        CREATE_TRY(hipMemcpy(e->d_twiddles, step_tw.data(), sizeof(rpf::cf) * step_tw.size(), hipMemcpyHostToDevice));
+        if (e->has_window)
+            CREATE_TRY(hipMemcpy(e->d_window, window_t.data(), sizeof(float) * window_t.size(), hipMemcpyHostToDevice));
     } else {
         CREATE_TRY(rpf::plan_launch(e->N, e->variant, e->has_window, true, e->device, &e->plan));
         rpf::LaunchInfo tmp;

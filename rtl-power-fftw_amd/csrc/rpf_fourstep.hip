@@ -12,7 +12,10 @@
 //        column FFTs -- 8 points per lane, so N1/8 lanes per column and 512/N1
 //        columns side by side in one wave -- with wave-local LDS exchanges (no
 //        s_barrier), multiplies by W_N^{n2 k1} and writes Y[frame][n2][k1] as
-//        coalesced rows.  (-1)^n = (-1)^n2 is a per-column constant.
+//        coalesced rows.  (-1)^n = (-1)^n2 is a per-column constant.  The inter-step
+//        twiddles and the window are read from tables the host lays out in the
+//        kernel's own lane order (lane_ordered_twiddles / transposed_window below), so
+//        that a wave's load is one contiguous run instead of a 64-line gather.
 //   K2b fourstep_rows_kernel  workgroup (k1 tile of 16*(512/N2) rows, frame group):
 //        loads the [N2 n2][tile k1] slab of Y (whole 128-byte lines), every
 //        wavefront owns 512/N2 rows for the whole launch: N2-point FFT over n2,
@@ -140,11 +143,10 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_cols_kernel(const uint8_t* __
                     *reinterpret_cast<const uint16_t*>(raw + 4 * (n1 * kRowDwords + (cl >> 1)) + 2 * (cl & 1));
                 const cf v = iq_plus_2p23(iq);
                 if constexpr (BLU) {
-                    const int n = N2 * n1 + c;
-                    x[a] = cf{0.0f, 0.0f};
-                    if (n < n_true) x[a] = cmul(v - (kTwo23 + 127.0f), g[n]);
+                    // g is zero past the end of the frame (whatever the unread LDS bytes hold is finite)
+                    x[a] = cmul(v - (kTwo23 + 127.0f), g[static_cast<size_t>(c) * N1 + n1]);
                 } else if constexpr (WINDOW) {
-                    const float w = window[static_cast<size_t>(N2) * n1 + c] * sgn;
+                    const float w = window[static_cast<size_t>(c) * N1 + n1] * sgn;
                     x[a] = (v - (kTwo23 + 127.0f)) * w;
                 } else {
                     x[a] = v * sgn + off;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_cols_kernel(const uint8_t* __
 #pragma unroll
             for (int a = 0; a < G::P; ++a) {
                 const int k1 = bin_of<G>(t, a);
-                slab[G::slot(k1)] = cmul(x[a], twN[c * k1]);
+                slab[G::slot(k1)] = cmul(x[a], twN[static_cast<size_t>(c) * N1 + T * a + t]);
             }
             exchange_sync<false>();
             cf* const yrow = Y + (static_cast<size_t>(f) * N2 + c) * N1;
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(kWG, 4) void bluestein_mid_kernel(const cf* __restr
 #pragma unroll
         for (int a = 0; a < G::P; ++a) {
             const int k2 = bin_of<G>(t, a);
-            cf z = cmul(x[a], bhat[k1 + N1 * k2]);
+            cf z = cmul(x[a], bhat[static_cast<size_t>(k1) * N2 + T * a + t]);
             z.y = -z.y;
             slab[G::slot(k2)] = z;
         }
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(kWG, 4) void bluestein_mid_kernel(const cf* __restr
 #pragma unroll
         for (int a = 0; a < G::P; ++a) {
             const int q1 = bin_of<G>(t, a);
-            slab[G::slot(q1)] = cmul(x[a], twM[k1 * q1]);    // k1 q1 < M: no reduction needed
+            slab[G::slot(q1)] = cmul(x[a], twM[static_cast<size_t>(k1) * N2 + T * a + t]);
         }
         exchange_sync<false>();
         cf* const row = Y2 + (static_cast<size_t>(f) * N1 + k1) * N2;
@@ -306,15 +308,44 @@ __global__ __launch_bounds__(kWG, 4) void bluestein_mid_kernel(const cf* __restr
     }
 }
 
+
+// ---- host: tables in lane order --------------------------------------------
+// out[r * LEN + T a + t] = master[(r * bin_of<G>(t, a) * step) mod master_len]: row r of the
+// inter-step twiddles W^{r k} in the order the lanes of a Geom<LEN, 8> transform hold bin k.
+template <class G>
+void lane_ordered_rows(const cf* master, size_t master_len, size_t step, int rows, std::vector<cf>& out)
+{
+    out.resize(static_cast<size_t>(rows) * G::N);
+    for (int r = 0; r < rows; ++r)
+        for (int a = 0; a < G::P; ++a)
+            for (int t = 0; t < G::T; ++t)
+                out[static_cast<size_t>(r) * G::N + G::T * a + t] =
+                    master[(static_cast<size_t>(r) * bin_of<G>(t, a) * step) % master_len];
+}
+// out[r * LEN + T a + t] = table[r + rows * bin_of<G>(t, a)]
+template <class G>
+void lane_ordered_cols(const cf* table, int rows, std::vector<cf>& out)
+{
+    out.resize(static_cast<size_t>(rows) * G::N);
+    for (int r = 0; r < rows; ++r)
+        for (int a = 0; a < G::P; ++a)
+            for (int t = 0; t < G::T; ++t)
+                out[static_cast<size_t>(r) * G::N + G::T * a + t] = table[r + static_cast<size_t>(rows) * bin_of<G>(t, a)];
+}
+
 // ---------------------------------------------------------------- dispatch --
 using ColsFn = void (*)(const uint8_t*, int, const cf*, const cf*, const float*, cf*, int, const cf*);
 using MidFn = void (*)(const cf*, int, const cf*, const cf*, const cf*, cf*);
 using RowsFn = void (*)(const cf*, int, const cf*, double*, int);
 
+using RowsTableFn = void (*)(const cf*, size_t, size_t, int, std::vector<cf>&);
+using ColsTableFn = void (*)(const cf*, int, std::vector<cf>&);
+
 struct SplitInfo {
     int N, N1, N2, cols_lds, rows_lds, batch, groups, row_tiles;
     ColsFn cols[2][2];   // [window][dma]
     RowsFn rows;
+    RowsTableFn step_twiddles;   // W_N^{n2 k1} in K2a's lane order
 };
 
 template <int N1, int N2>
@@ -324,7 +355,7 @@ SplitInfo make_split()
     return SplitInfo{S::N, N1, N2, S::COLS_LDS, S::ROWS_LDS, S::BATCH, S::GROUPS, S::ROW_TILES,
                      {{fourstep_cols_kernel<S, false, false>, fourstep_cols_kernel<S, false, true>},
                       {fourstep_cols_kernel<S, true, false>, fourstep_cols_kernel<S, true, true>}},
-                     fourstep_rows_kernel<S>};
+                     fourstep_rows_kernel<S>, lane_ordered_rows<typename S::GA>};
 }
 
 const SplitInfo kSplits[] = {
@@ -348,6 +379,9 @@ struct BluSplitInfo {
     ColsFn cols[2];   // [dma]
     MidFn mid;
     RowsFn rows;      // on the transposed split
+    RowsTableFn step_twiddles;    // W_M^{n2 k1} in K2a's lane order (rows n2 < M2)
+    RowsTableFn step_twiddles2;   // W_M^{k1 q1} in the mid kernel's lane order (rows k1 < M1)
+    ColsTableFn kernel_spectrum;  // bhat[k1 + M1 k2] in the mid kernel's lane order
 };
 
 template <int M1, int M2>
@@ -358,7 +392,8 @@ BluSplitInfo make_blu_split()
     return BluSplitInfo{S::N, M1, M2, S::COLS_LDS, S::ROWS_LDS, SR::ROWS_LDS, S::BATCH, SR::GROUPS,
                         SR::ROW_TILES, S::ROW_TILES,
                         {fourstep_cols_kernel<S, false, false, true>, fourstep_cols_kernel<S, false, true, true>},
-                        bluestein_mid_kernel<S>, fourstep_rows_kernel<SR>};
+                        bluestein_mid_kernel<S>, fourstep_rows_kernel<SR>, lane_ordered_rows<typename S::GA>,
+                        lane_ordered_rows<typename S::GB>, lane_ordered_cols<typename S::GB>};
 }
 
 const BluSplitInfo kBluSplits[] = {
@@ -399,6 +434,23 @@ int fourstep_sub_lengths(int N, int* n1, int* n2)
     *n1 = s->N1;
     *n2 = s->N2;
     return 1;
+}
+
+void fourstep_tables(int N, const float* window, std::vector<cf>& step_tw, std::vector<float>& window_t)
+{
+    const SplitInfo* s = find_split(N);
+    step_tw.clear();
+    window_t.clear();
+    if (!s) return;
+    std::vector<cf> master;
+    make_twiddles(N, master);
+    s->step_twiddles(master.data(), master.size(), 1, s->N2, step_tw);       // n2 k1 < N
+    if (window) {
+        window_t.resize(N);
+        for (int c = 0; c < s->N2; ++c)
+            for (int n1 = 0; n1 < s->N1; ++n1)
+                window_t[static_cast<size_t>(c) * s->N1 + n1] = window[static_cast<size_t>(s->N2) * n1 + c];
+    }
 }
 
 hipError_t fourstep_prepare(int N, int device, LaunchInfo* li)
@@ -463,6 +515,21 @@ int bigblu_lengths(int N, int* M, int* m1, int* m2)
     return 1;
 }
 
+// g (N) and bhat (M) are bluestein_tables.h's; outputs are what launch_bigblu takes.
+void bigblu_tables(int N, const cf* g, const cf* bhat, std::vector<cf>& g_t, std::vector<cf>& bhat_t,
+                   std::vector<cf>& step_tw, std::vector<cf>& step_tw2)
+{
+    const BluSplitInfo* s = find_blu_split(N);
+    if (!s) return;
+    g_t.assign(static_cast<size_t>(s->M), cf{0.0f, 0.0f});                   // zero past the frame
+    for (int n = 0; n < N; ++n) g_t[static_cast<size_t>(n % s->M2) * s->M1 + n / s->M2] = g[n];
+    s->kernel_spectrum(bhat, s->M1, bhat_t);
+    std::vector<cf> master;
+    make_twiddles(s->M, master);
+    s->step_twiddles(master.data(), master.size(), 1, s->M2, step_tw);
+    s->step_twiddles2(master.data(), master.size(), 1, s->M1, step_tw2);
+}
+
 size_t bigblu_scratch_bytes(int N)      // Y and Y2, one after the other
 {
     const BluSplitInfo* s = find_blu_split(N);
@@ -501,8 +568,8 @@ hipError_t bigblu_prepare(int N, int device, LaunchInfo* li)
 }
 
 hipError_t launch_bigblu(int N, bool use_dma, const uint8_t* d_stream, long nframes, const cf* d_tw_m1,
-                         const cf* d_tw_m2, const cf* d_twM, const cf* d_g, const cf* d_bhat, cf* d_scratch,
-                         double* d_partial, int max_grid, hipStream_t stream)
+                         const cf* d_tw_m2, const cf* d_step_tw, const cf* d_step_tw2, const cf* d_g_t,
+                         const cf* d_bhat_t, cf* d_scratch, double* d_partial, int max_grid, hipStream_t stream)
 {
     const BluSplitInfo* s = find_blu_split(N);
     if (!s || nframes < 1) return hipErrorInvalidValue;
@@ -515,11 +582,12 @@ hipError_t launch_bigblu(int N, bool use_dma, const uint8_t* d_stream, long nfra
         const uint8_t* src = d_stream + static_cast<size_t>(done) * 2 * N;
         const int cols_grid = std::min(max_grid, nb * (s->M2 / kColTile));
         hipLaunchKernelGGL(s->cols[use_dma ? 1 : 0], dim3(cols_grid), dim3(kWG), s->cols_lds, stream, src, nb,
-                           d_tw_m1, d_twM, static_cast<const float*>(nullptr), Y, N, d_g);
+                           d_tw_m1, d_step_tw, static_cast<const float*>(nullptr), Y, N, d_g_t);
         hipError_t err = hipGetLastError();
         if (err != hipSuccess) return err;
         const int mid_grid = std::min(max_grid, nb * s->mid_tiles);
-        hipLaunchKernelGGL(s->mid, dim3(mid_grid), dim3(kWG), s->mid_lds, stream, Y, nb, d_tw_m2, d_bhat, d_twM, Y2);
+        hipLaunchKernelGGL(s->mid, dim3(mid_grid), dim3(kWG), s->mid_lds, stream, Y, nb, d_tw_m2, d_bhat_t, d_step_tw2,
+                           Y2);
         if ((err = hipGetLastError()) != hipSuccess) return err;
         // second transform's rows: over k1 (M1 points), tw table of length M1
         hipLaunchKernelGGL(s->rows, dim3(rows_grid), dim3(kWG), s->rows_lds, stream, Y2, nb, d_tw_m1, d_partial,

@@ -53,9 +53,13 @@ bool fourstep_supported(int N);
 size_t fourstep_scratch_bytes(int N);  // intermediate Y[batch][N2][N1] complex floats (128 MB)
 int fourstep_partial_slots(int N);     // partial spectra written by K2b (frame groups)
 int fourstep_sub_lengths(int N, int* n1, int* n2);
+// Host tables in the kernels' lane order: step_tw[n2][.] = W_N^{n2 k1} (N entries),
+// window_t[n2][n1] = window[N2 n1 + n2] (empty without a window).
+void fourstep_tables(int N, const float* window, std::vector<cf>& step_tw, std::vector<float>& window_t);
 hipError_t fourstep_prepare(int N, int device, LaunchInfo* li);
 // Frames [0, nframes) -> d_partial[slots][N] (overwritten); K3 then sums the slots.
-// d_tw_n1 / d_tw_n2: master twiddle tables of the two sub-transform lengths.
+// d_tw_n1 / d_tw_n2: master twiddle tables of the two sub-transform lengths;
+// d_twN / d_window: fourstep_tables' step_tw / window_t.
 hipError_t launch_fourstep(int N, bool window, bool use_dma, const uint8_t* d_stream, long nframes,
                            const cf* d_tw_n1, const cf* d_tw_n2, const cf* d_twN, const float* d_window,
                            cf* d_scratch, double* d_partial, int max_grid, hipStream_t stream);
@@ -66,10 +70,13 @@ int bigblu_lengths(int N, int* M, int* m1, int* m2);   // M = m1 * m2 = 2^ceil(l
 size_t bigblu_scratch_bytes(int N);    // two intermediates of 128 MB
 int bigblu_partial_slots(int N);       // partial spectra of M (not N) doubles each
 hipError_t bigblu_prepare(int N, int device, LaunchInfo* li);
-// d_tw_m1 / d_tw_m2 / d_twM: master twiddles of lengths m1, m2, M; d_g (N) / d_bhat (M): bluestein_tables.h
+// Host tables (each M entries, in the kernels' lane order) from bluestein_tables.h's g (N) and bhat (M).
+void bigblu_tables(int N, const cf* g, const cf* bhat, std::vector<cf>& g_t, std::vector<cf>& bhat_t,
+                   std::vector<cf>& step_tw, std::vector<cf>& step_tw2);
+// d_tw_m1 / d_tw_m2: master twiddles of lengths m1, m2; the rest: bigblu_tables' outputs.
 hipError_t launch_bigblu(int N, bool use_dma, const uint8_t* d_stream, long nframes, const cf* d_tw_m1,
-                         const cf* d_tw_m2, const cf* d_twM, const cf* d_g, const cf* d_bhat, cf* d_scratch,
-                         double* d_partial, int max_grid, hipStream_t stream);
+                         const cf* d_tw_m2, const cf* d_step_tw, const cf* d_step_tw2, const cf* d_g_t,
+                         const cf* d_bhat_t, cf* d_scratch, double* d_partial, int max_grid, hipStream_t stream);
 
 // Master twiddle table W_N^k = exp(-2 pi i k / N), k in [0,N), evaluated in
 // long double and rounded once to float.
