@@ -195,17 +195,30 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_rows_kernel(const cf* __restr
 #pragma unroll
     for (int a = 0; a < G::P; ++a) acc[a] = 0.0;
 
+    // The next frame's tile is fetched into registers while this one is transformed
+    // (one 1024-thread workgroup per CU: nothing else would overlap the two; a second
+    // tile in flight needs 16 more VGPRs than the 128 available -- measured: spills, slower).
+    constexpr int PER = N2 * S::ROW_TILE / kWG;
+    cf nxt[PER];
+    auto fetch = [&](int f) {
+        const cf* const yf = Y + static_cast<size_t>(f) * S::N + S::ROW_TILE * ktile;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = i * kWG + tid;
+            nxt[i] = yf[static_cast<size_t>(idx / S::ROW_TILE) * N1 + idx % S::ROW_TILE];
+        }
+    };
+    if (fg < nframes) fetch(fg);
 #pragma unroll 1
     for (int f = fg; f < nframes; f += ngroups) {
-        const cf* const yf = Y + static_cast<size_t>(f) * S::N + S::ROW_TILE * ktile;
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < N2 * S::ROW_TILE / kWG; ++i) {
+        for (int i = 0; i < PER; ++i) {
             const int idx = i * kWG + tid;
-            const int n2 = idx / S::ROW_TILE, j = idx % S::ROW_TILE;
-            tile[n2 * S::ROW_PITCH + j] = yf[static_cast<size_t>(n2) * N1 + j];
+            tile[(idx / S::ROW_TILE) * S::ROW_PITCH + idx % S::ROW_TILE] = nxt[i];
         }
         __syncthreads();
+        if (f + ngroups < nframes) fetch(f + ngroups);
         cf x[G::P];
 #pragma unroll
         for (int a = 0; a < G::P; ++a) x[a] = tile[(t + T * a) * S::ROW_PITCH + jrow];
