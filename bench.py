@@ -210,11 +210,13 @@ def main():
         roof = None
         if k1_ms:
             achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
-            traffic = None
+            traffic = measured_peak = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get("fft_accum_c2_hbm_bytes_per_launch")
+                    tj = json.load(open(tpath))
+                    traffic = tj.get("fft_accum_c2_hbm_bytes_per_launch")
+                    measured_peak = tj.get("measured_read_only_GBps")   # tools/hbm_read_bench.hip, same box type
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -222,6 +224,9 @@ def main():
                     "kernel": "fft_accum_kernel<N=4096,P=16>", "kernel_ms": k1_ms,
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "samples_per_s_kernel_only": N_BINS * REPEATS / (k1_ms * 1e-3)}
+            if measured_peak:
+                roof["measured_read_only_peak"] = measured_peak
+                roof["frac_of_measured_read_only"] = achieved / measured_peak
         out = {
             "metric": "IQ samples/s through FFT+|X|^2-accumulate",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,

@@ -17,4 +17,5 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OU
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o c2 -- $BENCH > $OUT/pmc_write.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/pmc_sq -o c2 -- $BENCH > $OUT/pmc_sq.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_lds -o c2 -- $BENCH > $OUT/pmc_lds.log 2>&1
+[ -x $GRAFT_REPO_ROOT/tools/hbm_read_bench ] && timeout 120 $GRAFT_REPO_ROOT/tools/hbm_read_bench > $OUT/hbm_read.txt 2>&1
 ls -R $OUT | head -40

@@ -69,6 +69,14 @@ if "WRITE_SIZE" in k1:
     traffic["fft_accum_c2_write_bytes_per_launch"] = k1["WRITE_SIZE"] * 1024.0
 if traffic:
     traffic["fft_accum_c2_hbm_bytes_per_launch"] = sum(traffic.values())
+    hb = os.path.join(src, "hbm_read.txt")
+    if os.path.exists(hb):            # tools/hbm_read_bench.hip: read-only stream > Infinity Cache
+        import re
+        m = re.search(r"read-only stream of (\d+) B: .* = (\d+) GB/s", open(hb).read())
+        if m:
+            traffic["measured_read_only_GBps"] = float(m.group(2))
+            traffic["measured_read_only_bytes"] = int(m.group(1))
+            shutil.copy(hb, os.path.join(dst, tag + "_hbm_read.txt"))
     traffic["source"] = "profiles/%s_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x2 per MI355X_MICROARCH.md)" % tag
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(dst, tag + "_counters.json"), "w"), indent=1)
