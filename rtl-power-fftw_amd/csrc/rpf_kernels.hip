@@ -444,11 +444,7 @@ const Variant kVariants[] = {
     make_variant<4096, 16, 3, 3, false, 0, false, 2, 0, true, false, 768>(8),   // one 768-thread workgroup per CU, 3 frames side by side
     make_variant<4096, 16, 3, 2, false, 0, false, 2, 0, true>(9),               // 256 threads, 3 (windowed: 2) workgroups per CU
     make_variant<4096, 16, 2, 2, false, 0, false, 2, 0, true>(10),              // 256 threads, 2 workgroups per CU
-    make_variant<4096, 16, 2, 2, false, 0, false, 4, 0, true, false, 512>(20),  // 512 threads, raw ring 4 deep
     make_variant<4096, 16, 2, 2, true, 0, false, 1, 0, true, false, 512>(26),   // 512 threads, double-buffered slab (no top barrier), raw ring 1
-    make_variant<4096, 16, 2, 2, false, 0, false, 1, 0, true, false, 512>(27),  // 512 threads, raw ring 1 (control for 26)
-    make_variant<4096, 16, 2, 2, false, 0, false, 3, 0, true, false, 512>(21),  // 512 threads, raw ring 3 deep
-    make_variant<4096, 16, 2, 2, false, 8, true, 2, 0, true, false, 512>(22),   // 512 threads, f32 batch accumulators
     make_variant<4096, 16, 3, 2, false, 0, false, 1, 0, true, true>(6),   // next frame prefetched in VGPRs, no LDS-DMA
     make_variant<4096, 16, 3, 3, false, 8, true, 1, 0, true, true>(7),    // same + float32 batch accumulate/partials
     make_variant<512, 8, 4, 4, false, 0, false, 4>(1),  make_variant<512, 8, 4, 4, false, 0, false, 8>(2),

@@ -1,0 +1,78 @@
+"""Randomised parity stress on the GPU box: random N (every kernel family), frame
+counts, window on/off, buffer sizes (queue path with straddling frames) and
+device-pointer alignments, each checked against float64 truth; repeated launches
+are checked bit-for-bit against each other (races show up as run-to-run
+differences).  python tools/gpu_stress.py [seconds] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import torch
+import rtl_power_fftw_amd as rpf
+from helpers import truth_f64, max_err_over_mean
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+dev = torch.device("cuda:0")
+POW2 = [64, 128, 256, 512, 1024, 2048, 4096, 8192]
+FOUR = [16384, 32768, 65536, 131072, 262144]
+t0 = time.time()
+ncase = 0
+worst = 0.0
+worst_case = None
+while time.time() - t0 < budget:
+    fam = rng.integers(0, 4)
+    if fam == 0:
+        N = int(rng.choice(POW2))
+    elif fam == 1:
+        N = int(rng.choice(FOUR))
+    elif fam == 2:
+        N = 2 * int(rng.integers(1, 2049))
+    else:
+        N = 2 * int(rng.integers(2049, 65536))
+    if rpf.load().rpf_supported_n(N) != 1:
+        continue
+    max_frames = max(2, min(3000, (24 << 20) // (2 * N)))
+    R = int(rng.integers(1, max_frames + 1))
+    windowed = bool(rng.integers(0, 2))
+    extra = int(rng.integers(0, N)) * 2
+    stream = rpf.synth.uniform_iq(int(rng.integers(1, 1 << 30)), N * R + extra // 2)
+    w = (rpf.synth.hann_window(N) + np.float32(0.25)) if windowed else None
+    offset = int(rng.choice([0, 0, 4, 16, 2, 64]))          # device pointer alignment
+    buf_len = int(rng.choice([16384, 65536, 1 << 20, 1638400])) if rng.integers(0, 3) == 0 else None
+    quota = R if rng.integers(0, 4) else int(rng.integers(1, R + 1))
+    d_raw = torch.empty(stream.size + 64, dtype=torch.uint8, device=dev)
+    d_in = d_raw[offset:offset + stream.size]
+    d_in.copy_(torch.from_numpy(stream))
+    outs = []
+    params = rpf.Params(N=N, window=windowed, repeats=quota, **({"buf_length": buf_len} if buf_len else {}))
+    try:
+        with rpf.Datastore(params, w) as ds:
+            for rep in range(3):
+                d_out = torch.full((N,), float("nan"), dtype=torch.float64, device=dev)
+                n = ds.accumulate_device(d_in.data_ptr(), stream.size, quota, d_out.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                outs.append(d_out.cpu().numpy())
+                assert n == quota, (n, quota)
+            host = None
+            if buf_len:
+                host, done = ds.accumulate(stream, quota)
+                assert done == quota
+    except Exception as ex:
+        print("FAIL N=%d R=%d quota=%d win=%d off=%d buf=%s: %r" % (N, R, quota, windowed, offset, buf_len, ex), flush=True)
+        sys.exit(1)
+    truth = truth_f64(N, stream, quota, w)
+    err = max_err_over_mean(outs[0], truth)
+    if err > worst:
+        worst, worst_case = err, (N, R, quota, windowed)
+    ok = err < 1.5e-6 and np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    if host is not None:
+        ok = ok and float(np.max(np.abs(host - outs[0]) / np.maximum(np.abs(outs[0]), 1e-300))) < 1e-12
+    ncase += 1
+    if not ok:
+        print("FAIL N=%d R=%d quota=%d win=%d off=%d buf=%s err=%.3e same=%s/%s" % (
+            N, R, quota, windowed, offset, buf_len, err, np.array_equal(outs[0], outs[1]), np.array_equal(outs[0], outs[2])), flush=True)
+        sys.exit(1)
+print("stress: %d cases in %.0f s, worst error over mean bin %.2e at (N, frames, quota, windowed) = %s: all within bounds"
+      % (ncase, time.time() - t0, worst, worst_case))
