@@ -6,7 +6,8 @@
 //   --------------------------                ------------------------
 //   rpf_buffer_acquire  <-- empty_  <---------  recycle after H2D copy done
 //   fill pinned buffer
-//   rpf_buffer_submit   --> occupied_ ------->  pop, hipMemcpyAsync H2D (copy stream)
+//   rpf_buffer_submit   --> occupied_ ------->  pop everything queued, hipMemcpyAsync H2D
+//                                               (copy stream) back to back
 //                                               into a device staging slot placed so
 //                                               that it continues the byte stream of
 //                                               the previous slot's unfinished frame,
@@ -44,7 +45,8 @@ struct HostBuffer {
 };
 
 struct StagingSlot {
-    uint8_t* base = nullptr;        // device memory: [head_room | buffer_capacity]
+    uint8_t* base = nullptr;        // device memory: [head_room | coalesce x buffer_capacity]
+    hipEvent_t copy_done = nullptr; // the group's H2D copies have finished (host buffers reusable)
     hipEvent_t kernel_done = nullptr;
     bool in_flight = false;
 };
@@ -96,8 +98,8 @@ struct rpf_engine {
     double* d_partial = nullptr;
     double* d_pwr = nullptr;
     size_t head_room = 0;                 // >= 2N, multiple of 256
+    size_t coalesce = 1;                  // host buffers one staging slot holds (= one transform launch)
     std::vector<StagingSlot> staging;
-    hipEvent_t copy_done = nullptr;
     rpf::LaunchInfo plan;                 // resident grid for this N
     rpf::LaunchInfo last;                 // last launch
     int last_slots = 0;                   // partial spectra left by the last transform
@@ -190,26 +192,58 @@ void worker_main(rpf_engine* e)
     const uint8_t* carry_src = nullptr;
     size_t slot_idx = 0;
     int64_t frames_issued = 0;    // == repeats_done once everything has drained
+    std::vector<HostBuffer*> group;
+    // The previous group's host buffers are handed back only after the next group's
+    // copies have been issued (when there is a next group already waiting), so the
+    // PCIe link does not idle for a host wake-up between groups.
+    std::vector<HostBuffer*> copying;
+    hipEvent_t copying_done = nullptr;
+    auto recycle = [&]() {
+        if (copying.empty()) return;
+        if (copying_done) {
+            hipError_t rerr = hipEventSynchronize(copying_done);
+            if (rerr != hipSuccess) bail(rerr, "hipEventSynchronize(copy_done)");
+        }
+        std::lock_guard<std::mutex> lk(e->status_mutex);
+        for (HostBuffer* b : copying) e->empty_buffers.push_back(b);   // datastore.cxx:91-94
+        copying.clear();
+        copying_done = nullptr;
+        e->status_change.notify_all();
+    };
 
     std::unique_lock<std::mutex> status_lock(e->status_mutex, std::defer_lock);
     while (true) {
         // Wait until we have a bufferful of data (datastore.cxx:54-64)
         status_lock.lock();
+        if (e->occupied_buffers.empty() && !copying.empty()) {
+            // nothing queued: the producer may be waiting for the very buffers we hold
+            status_lock.unlock();
+            recycle();
+            status_lock.lock();
+        }
         while (e->occupied_buffers.empty() && !e->acquisition_finished)
             e->status_change.wait(status_lock);
         if (e->occupied_buffers.empty()) {
             status_lock.unlock();
             break;   // acquisition finished
         }
-        HostBuffer* buffer = e->occupied_buffers.front();
-        e->occupied_buffers.pop_front();
+        // Everything the producer has queued so far (up to the staging slot's capacity)
+        // goes to the device as one group: copies back to back, ONE transform launch --
+        // the stream is the concatenation of the buffers in FIFO order either way.
+        group.clear();
+        while (!e->occupied_buffers.empty() && group.size() < e->coalesce) {
+            group.push_back(e->occupied_buffers.front());
+            e->occupied_buffers.pop_front();
+        }
         status_lock.unlock();
 
+        size_t total = 0;
+        for (HostBuffer* b : group) total += b->size;
         // datastore.cxx:67: once the quota is met the rest of the stream is ignored
-        if (e->worker_rc == RPF_OK && frames_issued < e->repeats && buffer->size > 0) {
+        if (e->worker_rc == RPF_OK && frames_issued < e->repeats && total > 0) {
             StagingSlot& slot = e->staging[slot_idx];
             slot_idx = (slot_idx + 1) % e->staging.size();
-            // The slot is free once its own kernel AND the next buffer's carry copy
+            // The slot is free once its own kernel AND the next group's carry copy
             // (which read its tail) are done; the latter precedes the next slot's
             // kernel_done in stream order.
             StagingSlot& after = e->staging[slot_idx];
@@ -222,20 +256,24 @@ void worker_main(rpf_engine* e)
             // new bytes go right after the head room; the carried partial frame
             // is placed immediately in front of them
             uint8_t* dst = slot.base + e->head_room;
-            err = hipMemcpyAsync(dst, buffer->data, buffer->size, hipMemcpyHostToDevice,
-                                 e->copy_stream);
-            if (err != hipSuccess) bail(err, "hipMemcpyAsync(H2D)");
-            err = hipEventRecord(e->copy_done, e->copy_stream);
+            size_t off = 0;
+            for (HostBuffer* b : group) {
+                if (b->size == 0) continue;
+                err = hipMemcpyAsync(dst + off, b->data, b->size, hipMemcpyHostToDevice, e->copy_stream);
+                if (err != hipSuccess) bail(err, "hipMemcpyAsync(H2D)");
+                off += b->size;
+            }
+            err = hipEventRecord(slot.copy_done, e->copy_stream);
             if (err != hipSuccess) bail(err, "hipEventRecord(copy_done)");
             if (carry) {
                 err = hipMemcpyAsync(dst - carry, carry_src, carry, hipMemcpyDeviceToDevice,
                                      e->compute_stream);
                 if (err != hipSuccess) bail(err, "hipMemcpyAsync(carry)");
             }
-            err = hipStreamWaitEvent(e->compute_stream, e->copy_done, 0);
+            err = hipStreamWaitEvent(e->compute_stream, slot.copy_done, 0);
             if (err != hipSuccess) bail(err, "hipStreamWaitEvent");
 
-            const size_t avail = carry + buffer->size;
+            const size_t avail = carry + total;
             int64_t nframes = static_cast<int64_t>(avail / frame_bytes);
             nframes = std::min<int64_t>(nframes, e->repeats - frames_issued);
             if (e->worker_rc == RPF_OK && nframes > 0) {
@@ -250,21 +288,23 @@ void worker_main(rpf_engine* e)
             err = hipEventRecord(slot.kernel_done, e->compute_stream);
             if (err != hipSuccess) bail(err, "hipEventRecord(kernel_done)");
             slot.in_flight = true;
-            // the unfinished frame (if any) stays in this slot until the next buffer
+            // the unfinished frame (if any) stays in this slot until the next group
             const size_t consumed = static_cast<size_t>(nframes) * frame_bytes;
             carry = (frames_issued < e->repeats) ? (avail - consumed) % frame_bytes : 0;
-            carry_src = dst + buffer->size - carry;
-            // the pinned buffer may be refilled as soon as its H2D copy is done
-            err = hipEventSynchronize(e->copy_done);
-            if (err != hipSuccess) bail(err, "hipEventSynchronize(copy_done)");
+            carry_src = dst + total - carry;
+            // the pinned buffers may be refilled as soon as their H2D copies are done:
+            // the previous group's now (its copies precede ours on the copy stream, and
+            // ours are already queued behind them), this group's one iteration later
+            recycle();
+            copying = group;
+            copying_done = slot.copy_done;
+        } else {
+            recycle();
+            copying = group;          // nothing was copied: returned at the next recycle()
+            copying_done = nullptr;
         }
-
-        // datastore.cxx:91-94
-        status_lock.lock();
-        e->empty_buffers.push_back(buffer);
-        e->status_change.notify_all();
-        status_lock.unlock();
     }
+    recycle();
 
     err = hipStreamSynchronize(e->compute_stream);
     if (err != hipSuccess) bail(err, "hipStreamSynchronize");
@@ -291,8 +331,8 @@ void release_device(rpf_engine* e)
     for (auto& s : e->staging) {
         if (s.base) (void)hipFree(s.base);
         if (s.kernel_done) (void)hipEventDestroy(s.kernel_done);
+        if (s.copy_done) (void)hipEventDestroy(s.copy_done);
     }
-    if (e->copy_done) (void)hipEventDestroy(e->copy_done);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->compute_stream) (void)hipStreamDestroy(e->compute_stream);
     for (auto& b : e->pool)
@@ -376,7 +416,6 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
     CREATE_TRY(hipSetDevice(e->device));
     CREATE_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
     CREATE_TRY(hipStreamCreateWithFlags(&e->compute_stream, hipStreamNonBlocking));
-    CREATE_TRY(hipEventCreateWithFlags(&e->copy_done, hipEventDisableTiming));
 
     // "plan": twiddle table on the device (where fftwf_plan_dft_1d stands, datastore.cxx:32)
     std::vector<rpf::cf> tw;
@@ -468,12 +507,15 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
     }
     // device staging ring: head room for a carried partial frame + one buffer
     e->head_room = ((2 * static_cast<size_t>(e->N)) + 255) / 256 * 256;
+    // a slot holds as many queued buffers as fit 64 MB (at least one, at most the pool)
+    e->coalesce = std::max<size_t>(1, std::min<size_t>(e->n_buffers, (64u << 20) / e->buffer_capacity));
     e->staging.resize(3);
     for (auto& s : e->staging) {
         void* p = nullptr;
-        CREATE_TRY(hipMalloc(&p, e->head_room + e->buffer_capacity));
+        CREATE_TRY(hipMalloc(&p, e->head_room + e->coalesce * e->buffer_capacity));
         s.base = static_cast<uint8_t*>(p);
         CREATE_TRY(hipEventCreateWithFlags(&s.kernel_done, hipEventDisableTiming));
+        CREATE_TRY(hipEventCreateWithFlags(&s.copy_done, hipEventDisableTiming));
     }
 #undef CREATE_TRY
     *out = e;
