@@ -72,3 +72,46 @@ def test_c5_eight_hop_scan_sharded_like_multi_gpu(c2):
                 first, count = rpf.sharding.shard_frames(per_hop, 2, rank)
                 acc += device_run(ds, d_in, hop * per_hop + first, count, dev)
             assert max_rel(acc, whole) < 1e-12
+
+
+def test_c4_full_size_properties():
+    """Config C4: N = 262144 bins x 1000 repeats (524 MB of IQ, four-step kernels),
+    frames straddling the reference's 1.6 MB buffers in the queue path."""
+    import torch
+    n4, r4 = 262144, 1000
+    dev = torch.device("cuda:0")
+    stream = rpf.synth.noise_tones_iq(4, n4 * r4)
+    d_in = torch.from_numpy(stream).to(dev)
+
+    def run(ds, first, frames):
+        out = torch.empty(n4, dtype=torch.float64, device=dev)
+        n = ds.accumulate_device(d_in.data_ptr() + 2 * n4 * first, 2 * n4 * frames, frames, out.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert n == frames
+        return out.cpu().numpy()
+
+    with rpf.Datastore(rpf.Params(N=n4, repeats=r4, buf_length=1638400)) as ds:
+        full = run(ds, 0, r4)
+        a, b = run(ds, 0, 337), run(ds, 337, r4 - 337)
+        assert max_rel(a + b, full) < 1e-12                       # additivity over frames
+        assert np.array_equal(full, run(ds, 0, r4))               # reproducible
+        x = stream.astype(np.int64).reshape(-1, 2) - 127
+        energy = float(n4) * float(np.sum(x * x))
+        assert abs(full.sum() / energy - 1.0) < 1e-7              # Parseval, right side exact
+        # the oracle on a few frames.  Noise-only bytes: with C4's tones (32768 x the noise
+        # floor per bin at this N) any two float32 FFTs -- FFTW plans included -- differ by a
+        # few 1e-6 of the floor around them (DESIGN.md 6), which says nothing about the kernels.
+        head = 6
+        noise = rpf.synth.uniform_iq(404, n4 * head)
+        d_noise = torch.from_numpy(noise).to(dev)
+        out = torch.empty(n4, dtype=torch.float64, device=dev)
+        assert ds.accumulate_device(d_noise.data_ptr(), noise.size, head, out.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream) == head
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        want, _ = oracle_accumulate(n4, noise, head, None)
+        floor = np.median(want)
+        assert float(np.max(np.abs(got - want) / np.maximum(want, floor))) < 1e-6
+        host, done = ds.accumulate(stream, r4)                    # 320 buffers of 3.125 frames
+        assert done == r4 and max_rel(host, full) < 1e-12
