@@ -51,7 +51,7 @@ const Spec kSpecs[] = {
     {'w', "window", Kind::Text, "file|-", "Use window function, from file or stdin."},
     // additive (not in the reference)
     {0, "input", Kind::Text, "file|-", "Replay interleaved 8-bit IQ samples from a file or stdin."},
-    {0, "synthetic", Kind::Int64, "seed", "Use the built-in synthetic receiver (default)."},
+    {0, "synthetic", Kind::Int64, "seed", "Use the built-in synthetic receiver instead of a dongle."},
     {0, "gpu", Kind::Int, "ordinal", "HIP device to run on."},
     {'h', "help", Kind::Flag, "", "Displays usage information and exits."},
     {0, "version", Kind::Flag, "", "Displays version information and exits."},
@@ -253,6 +253,7 @@ Options parse_command_line(int argc, const char* const* argv)
         o.session_duration_isSet = true;
     }
     if (p.has("input")) o.input_file = p.get("input");
+    o.synthetic = p.has("synthetic");
     if (p.has("synthetic")) o.synthetic_seed = static_cast<uint64_t>(to_number<int64_t>(*find_spec("--synthetic"), p.get("synthetic")));
     return o;
 }

@@ -4,7 +4,8 @@
 // small table-driven parser (TCLAP is not available here).  Additive options
 // select the sample source, since there is no dongle next to an MI355X:
 //   --input <file|->      replay interleaved u8 IQ from a file / stdin
-//   --synthetic <seed>    built-in receiver-like generator (the default, seed 2)
+//   --synthetic <seed>    built-in receiver-like generator
+//   (neither: a live RTL-SDR dongle through librtlsdr, like the reference)
 //   --gpu <ordinal>       HIP device
 #ifndef RPF_HOST_OPTIONS_H
 #define RPF_HOST_OPTIONS_H
@@ -43,7 +44,8 @@ struct Options : Params {
     int finalfreq = 0;
     std::string matrix_file, bin_file, meta_file;
     // additive
-    std::string input_file;          // empty = synthetic
+    std::string input_file;          // --input
+    bool synthetic = false;          // --synthetic given
     uint64_t synthetic_seed = 2;
     bool show_help = false, show_version = false;
 };

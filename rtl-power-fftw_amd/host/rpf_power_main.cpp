@@ -50,8 +50,10 @@ int run(int argc, char** argv)
     AuxData aux(options);
 
     std::unique_ptr<SampleSource> source;
+    RtlSdrSource* dongle = nullptr;
     if (!options.input_file.empty()) source.reset(new FileSource(options.input_file));
-    else source.reset(new SyntheticSource(options.synthetic_seed));
+    else if (options.synthetic) source.reset(new SyntheticSource(options.synthetic_seed));
+    else source.reset(dongle = new RtlSdrSource(options.dev_index));   // rtl_power_fftw.cxx:65
 
     if (options.endless) options.session_duration_isSet = false;
     time_t exit_time = 0;
@@ -59,7 +61,23 @@ int run(int argc, char** argv)
         exit_time = static_cast<int>(options.session_duration);
         std::cerr << "Scan session duration: " << exit_time << " seconds" << std::endl;
     }
-    source->set_frequency(options.cfreq);
+    if (dongle) {
+        // rtl_power_fftw.cxx:77-97: nearest available gain, provisional tuning, ppm
+        dongle->print_gains();
+        const int gain = dongle->nearest_gain(options.gain);
+        std::cerr << "Selected nearest available gain: " << gain << " (" << 0.1 * gain << " dB)" << std::endl;
+        dongle->set_gain(gain);
+        try {
+            dongle->set_frequency(options.cfreq);
+        } catch (RPFexception&) {
+        }
+        if (options.ppm_error != 0) {
+            dongle->set_freq_correction(options.ppm_error);
+            std::cerr << "PPM error set to: " << options.ppm_error << std::endl;
+        }
+    } else {
+        source->set_frequency(options.cfreq);
+    }
     source->set_sample_rate(static_cast<uint32_t>(options.sample_rate));
     const int actual_samplerate = source->sample_rate();
     std::cerr << "Actual sample rate: " << actual_samplerate << " Hz" << std::endl;

@@ -1,13 +1,15 @@
 // sample_source.h -- where the IQ bytes come from.  Stands where `class Rtlsdr`
 // stands in the reference (/root/reference/src/device.h:28-54): tune, report the
-// sample rate, fill a Buffer.  There is no dongle next to an MI355X, so the two
-// implementations replay a byte stream (file / stdin) or synthesise one.
+// sample rate, fill a Buffer.  Three implementations: a live dongle through
+// librtlsdr resolved at run time (no link-time dependency: there is none next
+// to an MI355X), a replayed byte stream (file / stdin) and a synthetic receiver.
 #ifndef RPF_HOST_SAMPLE_SOURCE_H
 #define RPF_HOST_SAMPLE_SOURCE_H
 
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "datastore.h"
 
@@ -57,6 +59,30 @@ public:
 private:
     uint64_t base_seed_, seed_;
     uint64_t position_ = 0;          // complex samples produced since the last tune
+};
+
+// A live RTL-SDR dongle, the reference's only source (src/device.cxx:29-151).
+// librtlsdr is dlopen()ed (RPF_RTLSDR_LIB, else librtlsdr.so.0 / librtlsdr.so) and
+// its 13 entry points resolved by name; a missing library or no dongle ends the
+// program with the reference's own NoDeviceFound exit code.
+class RtlSdrSource : public SampleSource {
+public:
+    explicit RtlSdrSource(int dev_index);
+    ~RtlSdrSource() override;
+    void set_sample_rate(uint32_t rate) override;
+    int sample_rate() const override;
+    void set_frequency(int64_t hz) override;
+    int64_t frequency() const override;
+    bool read(Buffer& buffer) override;
+    std::vector<int> gains() const;              // tenths of a dB
+    int nearest_gain(int gain) const;
+    void print_gains() const;
+    void set_gain(int gain);
+    void set_freq_correction(int ppm_error);
+private:
+    struct Api;
+    Api* api_ = nullptr;
+    void* dev_ = nullptr;
 };
 
 }  // namespace rpf_host

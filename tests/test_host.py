@@ -19,6 +19,9 @@ CLI = os.path.join(HOST_DIR, "rpf_power")
 def host():
     if not (os.path.exists(os.path.join(HOST_DIR, "librpf_host.so")) and os.path.exists(CLI)):
         subprocess.run(["make", "-C", HOST_DIR], check=True)
+    fake_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rtlsdr")
+    if not os.path.exists(os.path.join(fake_dir, "libfake_rtlsdr.so")):
+        subprocess.run(["make", "-C", fake_dir], check=True)
     import torch  # noqa: F401  (same HIP runtime for librpf_engine.so, see _lib.load)
     lib = ctypes.CDLL(os.path.join(HOST_DIR, "librpf_host.so"))
     lib.rpf_host_parse_frequency.restype = ctypes.c_longlong
@@ -208,8 +211,49 @@ def test_cli_exit_codes_without_running_anything(host):
     assert r.returncode == 0 and "--bins" in r.stdout and "--strict-time" in r.stdout
     import torch
     if not torch.cuda.is_available():
-        r = subprocess.run([CLI, "-b", "512", "-n", "10", "-q"], capture_output=True, text=True)
+        r = subprocess.run([CLI, "-b", "512", "-n", "10", "-q", "--synthetic", "2"], capture_output=True, text=True)
         assert r.returncode == 7 and "no CPU path" in r.stderr              # HardwareError, no fallback
+
+
+# ------------------------------------------------------------------ live dongle (dlopen of librtlsdr)
+FAKE_RTLSDR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rtlsdr", "libfake_rtlsdr.so")
+
+
+def _live_env(tmp_path, **extra):
+    env = dict(os.environ, RPF_RTLSDR_LIB=FAKE_RTLSDR, FAKE_RTLSDR_LOG=str(tmp_path / "calls.log"))
+    env.update({k: str(v) for k, v in extra.items()})
+    return env
+
+
+def test_cli_without_a_source_wants_a_dongle(host, tmp_path):
+    """Neither --input nor --synthetic: the reference's behaviour, a live RTL-SDR
+    (device.cxx:29-50) -- and the reference's exit codes when there is none."""
+    # no librtlsdr at all (nothing of that name in this image)
+    r = subprocess.run([CLI, "-b", "512"], capture_output=True, text=True,
+                       env=dict(os.environ, RPF_RTLSDR_LIB="/nonexistent/librtlsdr.so"))
+    assert r.returncode == 1 and "No RTL-SDR compatible devices found" in r.stderr
+    # library present, no dongle plugged in
+    r = subprocess.run([CLI, "-b", "512"], capture_output=True, text=True, env=_live_env(tmp_path, FAKE_RTLSDR_COUNT=0))
+    assert r.returncode == 1 and "No RTL-SDR compatible devices found." in r.stderr
+    # one dongle, device index 3 asked for
+    r = subprocess.run([CLI, "-b", "512", "-d", "3"], capture_output=True, text=True, env=_live_env(tmp_path))
+    assert r.returncode == 2 and "Invalid RTL device number. Only 1 devices available." in r.stderr
+
+
+def test_cli_dongle_setup_sequence(host, tmp_path):
+    """rtl_power_fftw.cxx:77-101: gains printed, nearest gain selected in manual
+    mode, provisional tuning, ppm, sample rate read back -- recorded by the test
+    double.  (On a box without a GPU the run then stops at the engine: exit 7.)"""
+    env = _live_env(tmp_path, FAKE_RTLSDR_RATE_OFFSET=-3)
+    r = subprocess.run([CLI, "-b", "512", "-n", "10", "-g", "300", "-p", "12", "-f", "1420405752", "-r", "2400000"],
+                       capture_output=True, text=True, env=env)
+    assert "Available gains (in 1/10th of dB): 0, 9, 14, 27," in r.stderr
+    assert "Selected nearest available gain: 297 (29.7 dB)" in r.stderr
+    assert "PPM error set to: 12" in r.stderr
+    assert "Actual sample rate: 2399997 Hz" in r.stderr
+    calls = (tmp_path / "calls.log").read_text().split("\n")
+    assert calls[:6] == ["open 0", "gain_mode 1", "gain 297", "freq 1420405752", "ppm 12", "rate 2400000"]
+    assert r.returncode in (0, 7)          # 7: no HIP device here
 
 
 # ------------------------------------------------------------------ GPU: end to end
@@ -273,3 +317,21 @@ def test_cli_file_replay_window_baseline_and_matrix(host, tmp_path):
     met = (tmp_path / "scan.met").read_text().split("\n")
     assert met[0] == "%d # frequency bins (columns)" % N and met[1] == "1 # scans (rows)"
     assert met[4] == "%d # stepFreq (Hz)" % (2000000 // N)
+
+
+@pytest.mark.gpu
+def test_cli_live_dongle_equals_replay_of_the_same_bytes(host, tmp_path):
+    """The live path (librtlsdr through dlopen, here the file-backed test double)
+    and --input replay of the same bytes print the same spectra."""
+    N, R = 1024, 64
+    stream = rpf.synth.noise_tones_iq(11, N * R + 4096)
+    iq = tmp_path / "iq.u8"
+    iq.write_bytes(stream.tobytes())
+    common = ["-b", str(N), "-n", str(R), "-f", "433920000", "-q"]
+    live = subprocess.run([CLI] + common, capture_output=True, text=True, env=_live_env(tmp_path, FAKE_RTLSDR_FILE=iq))
+    replay = subprocess.run([CLI] + common + ["--input", str(iq)], capture_output=True, text=True)
+    assert live.returncode == 0 and replay.returncode == 0, live.stderr + replay.stderr
+    assert _data_lines(live.stdout) == _data_lines(replay.stdout)
+    assert len(_data_lines(live.stdout)) >= N
+    calls = (tmp_path / "calls.log").read_text().split("\n")
+    assert "freq 433920000" in calls and calls[-2] == "close"
