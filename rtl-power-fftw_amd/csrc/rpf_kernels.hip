@@ -444,6 +444,7 @@ const Variant kVariants[] = {
     make_variant<4096, 16, 3, 3, false, 0, false, 2, 0, true, false, 768>(8),   // one 768-thread workgroup per CU, 3 frames side by side
     make_variant<4096, 16, 3, 2, false, 0, false, 2, 0, true>(9),               // 256 threads, 3 (windowed: 2) workgroups per CU
     make_variant<4096, 16, 2, 2, false, 0, false, 2, 0, true>(10),              // 256 threads, 2 workgroups per CU
+    make_variant<4096, 16, 2, 2, false, 8, false, 2, 0, true, false, 512>(22),  // 512 threads, float32 batch accumulate, f64 partials
     make_variant<4096, 16, 2, 2, true, 0, false, 1, 0, true, false, 512>(26),   // 512 threads, double-buffered slab (no top barrier), raw ring 1
     make_variant<4096, 16, 3, 2, false, 0, false, 1, 0, true, true>(6),   // next frame prefetched in VGPRs, no LDS-DMA
     make_variant<4096, 16, 3, 3, false, 8, true, 1, 0, true, true>(7),    // same + float32 batch accumulate/partials
@@ -465,6 +466,13 @@ const Variant kVariants[] = {
     make_variant<4096, 16, 3, 2, false, 0, false, 2, 12, true>(17),   // butterflies + accumulate only (no exchanges, no staging)
     make_variant<4096, 16, 3, 2, false, 0, false, 2, 13, true>(18),   // butterflies only
     make_variant<4096, 16, 3, 2, false, 0, false, 2, 14, true>(19),   // accumulate only (+ barriers, unpack)
+    // the same ablations on the default 512-thread configuration
+    make_variant<4096, 16, 2, 2, false, 0, false, 2, 1, true, false, 512>(31),    // no accumulate
+    make_variant<4096, 16, 2, 2, false, 0, false, 2, 2, true, false, 512>(32),    // no butterfly arithmetic
+    make_variant<4096, 16, 2, 2, false, 0, false, 2, 4, true, false, 512>(34),    // no LDS exchanges
+    make_variant<4096, 16, 2, 2, false, 0, false, 2, 8, true, false, 512>(38),    // no HBM staging
+    make_variant<4096, 16, 2, 2, false, 0, false, 2, 13, true, false, 512>(36),   // butterflies only
+    make_variant<4096, 16, 2, 2, false, 0, false, 2, 12, true, false, 512>(37),   // butterflies + accumulate only
 };
 
 const Variant* find_variant(int N, int vid)
