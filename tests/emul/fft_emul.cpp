@@ -165,7 +165,7 @@ extern "C" int rpf_emul_accumulate(int N, int P, const float* window, const uint
 {
 #define CASE(n, p) if (N == n && P == p) return run<n, p>(window, stream, nframes, pwr)
     CASE(64, 8); CASE(128, 8); CASE(256, 8); CASE(512, 8); CASE(1024, 8); CASE(4096, 8);
-    CASE(1024, 16); CASE(2048, 16); CASE(4096, 16); CASE(8192, 16); CASE(256, 16); CASE(512, 16);
+    CASE(1024, 16); CASE(2048, 16); CASE(4096, 16); CASE(8192, 16); CASE(256, 16); CASE(512, 16); CASE(128, 16);
 #undef CASE
     return -1;
 }

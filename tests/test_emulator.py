@@ -7,7 +7,7 @@ import pytest
 import rtl_power_fftw_amd as rpf
 from helpers import emul_accumulate, emul_bluestein, max_err_over_mean, max_rel, oracle_accumulate, truth_f64
 
-CASES = [(64, 8), (128, 8), (256, 8), (512, 8), (1024, 8), (4096, 8), (256, 16), (512, 16),
+CASES = [(64, 8), (128, 8), (256, 8), (512, 8), (1024, 8), (4096, 8), (128, 16), (256, 16), (512, 16),
          (1024, 16), (2048, 16), (4096, 16), (8192, 16)]
 
 
