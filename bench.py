@@ -49,18 +49,19 @@ def load_oracle():
     return lib
 
 
-def cpu_baseline(stream, pwr_gpu):
+def cpu_baseline(stream, pwr_gpu, window=None):
     """Time the CPU restatement (oracle, kind 'port') on this box's host cores on
     a bounded sample of the same workload, and check the GPU result against it."""
     lib = load_oracle()
     u8p = ctypes.POINTER(ctypes.c_uint8)
     dp = ctypes.POINTER(ctypes.c_double)
+    wp = window.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if window is not None else None
     pwr = np.zeros(N_BINS)
     done = ctypes.c_int64()
     passes = 0
     t0 = time.perf_counter()
     while True:
-        rc = lib.rpf_oracle_accumulate(N_BINS, None, 32, stream.ctypes.data_as(u8p), stream.size,
+        rc = lib.rpf_oracle_accumulate(N_BINS, wp, 32, stream.ctypes.data_as(u8p), stream.size,
                                        REPEATS, pwr.ctypes.data_as(dp), ctypes.byref(done))
         assert rc == 0 and done.value == REPEATS
         passes += 1
@@ -75,7 +76,7 @@ def cpu_baseline(stream, pwr_gpu):
     t0 = time.perf_counter()
     p2 = 0
     while True:
-        rc = lib.rpf_oracle_accumulate_mt(N_BINS, None, stream.ctypes.data_as(u8p), stream.size,
+        rc = lib.rpf_oracle_accumulate_mt(N_BINS, wp, stream.ctypes.data_as(u8p), stream.size,
                                           REPEATS, cores, pwr_mt.ctypes.data_as(dp), ctypes.byref(done))
         assert rc == 0
         p2 += 1
@@ -101,6 +102,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the per-step reduce even with one rank")
+    ap.add_argument("--workload", choices=["C2", "C3"], default="C2",
+                    help="C2 (default, the metric's configuration): rectangular window; C3: periodic Hann window")
     ap.add_argument("--event-every", type=int, default=8,
                     help="bracket the fused kernel with HIP events on every k-th timed step")
     args = ap.parse_args()
@@ -134,7 +137,9 @@ def main():
     # addresses and byte order, same statistics)
     bufs = [d_base] + [torch.roll(d_base, shifts=2 * N_BINS * (37 * i)) for i in range(1, nb)]
 
-    ds = rpf.Datastore(rpf.Params(N=N_BINS, repeats=REPEATS), device=dev.index or 0)
+    window = rpf.synth.hann_window(N_BINS) if args.workload == "C3" else None
+    ds = rpf.Datastore(rpf.Params(N=N_BINS, window=window is not None, repeats=REPEATS), window,
+                       device=dev.index or 0)
     # Multi-GPU exchange: the spectra of HOPS consecutive steps (= the
     # hops of one scan, config C5 has 8) meet in ONE reduce of HOPS*N doubles --
     # fewer, larger collectives -- issued asynchronously on a ring of blocks so that
@@ -205,7 +210,7 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * N_BINS * REPEATS * args.steps / elapsed
         k1_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else None
-        alg_bytes = 2 * N_BINS * REPEATS + 8 * N_BINS   # 2 B/sample + 8N accumulator
+        alg_bytes = 2 * N_BINS * REPEATS + 8 * N_BINS + (4 * N_BINS if window is not None else 0)
         info = ds.launch_info()
         roof = None
         if k1_ms:
@@ -215,7 +220,7 @@ def main():
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    traffic = tj.get("fft_accum_c2_hbm_bytes_per_launch")
+                    traffic = tj.get("fft_accum_%s_hbm_bytes_per_launch" % args.workload.lower())
                     measured_peak = tj.get("measured_read_only_GBps")   # tools/hbm_read_bench.hip, same box type
                 except Exception:
                     traffic = None
@@ -232,13 +237,14 @@ def main():
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: N=4096 bins x 10000 repeats per step per GPU, rectangular window, "
+            "config": {"workload": "%s: N=4096 bins x 10000 repeats per step per GPU, %s window, " % (
+                args.workload, "periodic Hann" if window is not None else "rectangular") +
                                    "u8 IQ resident in HBM (%d replay buffers of %d B)" % (nb, stream_bytes),
                        "launch": info, "reduce": "one async RCCL reduce of 8 x 4096 f64 bins per 8 steps" if use_dist else "none"},
             "roofline": roof,
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(base, pwr_first)
+            out["cpu_baseline"] = cpu_baseline(base, pwr_first, window)
         print(json.dumps(out), flush=True)
 
     ds.close()

@@ -79,6 +79,23 @@ if traffic:
             shutil.copy(hb, os.path.join(dst, tag + "_hbm_read.txt"))
     traffic["source"] = "profiles/%s_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x2 per MI355X_MICROARCH.md)" % tag
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+# config C3 (windowed kernel), if gpu_profile.sh captured it
+c3 = {}
+for sub in ("c3_pmc_fetch", "c3_pmc_write"):
+    pth = os.path.join(src, sub, "c3_counter_collection.csv")
+    if os.path.exists(pth):
+        c3.update(means(pth).get("K1_fft_accum", {}))
+if "FETCH_SIZE" in c3 and "WRITE_SIZE" in c3:
+    traffic["fft_accum_c3_fetch_bytes_per_launch"] = c3["FETCH_SIZE"] * 1024.0 * 2.0
+    traffic["fft_accum_c3_write_bytes_per_launch"] = c3["WRITE_SIZE"] * 1024.0
+    traffic["fft_accum_c3_hbm_bytes_per_launch"] = (traffic["fft_accum_c3_fetch_bytes_per_launch"] +
+                                                    traffic["fft_accum_c3_write_bytes_per_launch"])
+    json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    out["K1_fft_accum_C3_windowed"] = c3
+for name in ("c3_trace/c3_kernel_stats.csv", "c3_bench.json"):
+    pth = os.path.join(src, name)
+    if os.path.exists(pth):
+        shutil.copy(pth, os.path.join(dst, tag + "_" + os.path.basename(name)))
 json.dump(out, open(os.path.join(dst, tag + "_counters.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 print(json.dumps(traffic, indent=1))
