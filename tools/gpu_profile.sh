@@ -23,5 +23,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3_trac
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/c3_pmc_fetch -o c3 -- $BENCH3 > $OUT/c3_pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/c3_pmc_write -o c3 -- $BENCH3 > $OUT/c3_pmc_write.log 2>&1
 (cd $GRAFT_REPO_ROOT && python bench.py --workload C3 --no-cpu-baseline > $OUT/c3_bench.json 2> $OUT/c3_bench.err)
+# config C4 (N = 262144 x 1000, four-step kernels)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_trace -o c4 -- python $GRAFT_REPO_ROOT/tools/gpu_c4.py 10 > $OUT/c4.json 2> $OUT/c4.err
 [ -x $GRAFT_REPO_ROOT/tools/hbm_read_bench ] && timeout 120 $GRAFT_REPO_ROOT/tools/hbm_read_bench > $OUT/hbm_read.txt 2>&1
 ls -R $OUT | head -40

@@ -92,7 +92,7 @@ if "FETCH_SIZE" in c3 and "WRITE_SIZE" in c3:
                                                     traffic["fft_accum_c3_write_bytes_per_launch"])
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     out["K1_fft_accum_C3_windowed"] = c3
-for name in ("c3_trace/c3_kernel_stats.csv", "c3_bench.json"):
+for name in ("c3_trace/c3_kernel_stats.csv", "c3_bench.json", "c4_trace/c4_kernel_stats.csv", "c4.json"):
     pth = os.path.join(src, name)
     if os.path.exists(pth):
         shutil.copy(pth, os.path.join(dst, tag + "_" + os.path.basename(name)))
