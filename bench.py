@@ -243,7 +243,7 @@ def main():
                        "launch": info, "reduce": "one async RCCL reduce of 8 x 4096 f64 bins per 8 steps" if use_dist else "none"},
             "roofline": roof,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # the CPU leg is timed at N=1 only
             out["cpu_baseline"] = cpu_baseline(base, pwr_first, window)
         print(json.dumps(out), flush=True)
 
