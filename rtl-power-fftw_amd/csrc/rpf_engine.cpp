@@ -714,7 +714,7 @@ int rpf_device_reduce(rpf_engine* e, double* d_pwr_out, void* hip_stream)
     if (e->last_slots < 1) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_reduce: nothing to reduce");
     HIP_TRY(e, rpf::launch_reduce(e->d_partial, e->last_slots, e->N, d_pwr_out,
                                   /*accumulate=*/false, static_cast<hipStream_t>(hip_stream),
-                                  e->plan.partial_f32));
+                                  e->plan.partial_f32, e->bigblu ? static_cast<size_t>(e->blu_M) : 0));
     return RPF_OK;
 }
 

@@ -151,6 +151,16 @@ def test_large_non_power_of_two_sizes_match_oracle(N, torch_dev):
         assert n == done == R
         assert np.array_equal(got, got_nodma)
         assert max_rel(host, got) < 1e-13
+        if not windowed:      # the two-call form the benchmark uses (fused launch, then reduce)
+            import torch
+            d_in = torch.from_numpy(np.ascontiguousarray(stream)).to(torch_dev)
+            d_out = torch.empty(N, dtype=torch.float64, device=torch_dev)
+            with rpf.Datastore(rpf.Params(N=N, repeats=R)) as ds3:
+                st = torch.cuda.current_stream().cuda_stream
+                assert ds3.device_fused(d_in.data_ptr(), stream.size, R, st) == R
+                ds3.device_reduce(d_out.data_ptr(), st)
+                torch.cuda.synchronize()
+            assert np.array_equal(d_out.cpu().numpy(), got)
         truth = truth_f64(N, stream, R, w)
         assert max_err_over_mean(got, truth) < PARITY
         o32, _ = oracle_accumulate(N, stream, R, w, 32)
