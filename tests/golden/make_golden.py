@@ -33,6 +33,9 @@ CASES = [
     # tower 3e4 x over the noise floor and no float32 FFT resolves the floor bins
     # of such a frame to 1e-6
     ("n262144_r2_uniform", 262144, 2, "uniform", 7, False),
+    ("n16384_r8_uniform", 16384, 8, "uniform", 8, True),           # smallest four-step size, windowed
+    ("n5000_r12_uniform", 5000, 12, "uniform", 9, False),          # large Bluestein path, M = 16384
+    ("n100000_r3_uniform", 100000, 3, "uniform", 10, False),       # large Bluestein path, M = 262144
 ]
 
 
@@ -54,7 +57,10 @@ def truth(N, stream, repeats, window):
 
 
 def main():
+    only = set(sys.argv[1:])          # optional: regenerate just these fixtures
     for name, N, R, gen, seed, win in CASES:
+        if only and name not in only:
+            continue
         stream = stream_for(gen, seed, N * R)
         window = rpf.synth.hann_window(N) if win else None
         pwr = truth(N, stream, R, window)

@@ -190,4 +190,4 @@ def golden_stream(g):
 
 GOLDEN_CASES = ["c1_n512_r100_uniform", "n512_r100_hann", "n4096_r64_noise", "n4096_r64_hann",
                 "n64_r33_uniform", "n1024_r17_noise", "n8192_r9_noise", "n500_r20_uniform",
-                "n262144_r2_uniform"]
+                "n262144_r2_uniform", "n16384_r8_uniform", "n5000_r12_uniform", "n100000_r3_uniform"]

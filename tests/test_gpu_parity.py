@@ -72,7 +72,10 @@ def test_device_path_matches_golden_vectors(name, torch_dev):
     if "stride" in g:                        # large-N fixtures keep every stride-th bin + the total
         st = int(g["stride"])
         assert err(got[::st], g["pwr"]) < (VS_TRUTH if R >= 16 else PARITY)
-        assert abs(got.sum() / float(g["total"]) - 1) < 1e-7
+        # total power: the butterflies' constant twiddles (sqrt(1/2), cos/sin(pi/8) as floats) are a
+        # hair inside the unit circle, a systematic -2e-8 per radix-16 pass that does not average out
+        # (DESIGN.md 6): about -1e-7 for one length-262144 transform, -2e-7 for Bluestein's two
+        assert abs(got.sum() / float(g["total"]) - 1) < 3e-7
     else:
         assert err(got, g["pwr"]) < (VS_TRUTH if R >= 16 else PARITY)
     assert max_rel(host, got) < 1e-13        # queue path and device path run the same kernels
