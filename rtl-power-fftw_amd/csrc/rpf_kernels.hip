@@ -501,11 +501,12 @@ BluesteinVariant make_bluestein()
 }
 const BluesteinVariant kBluestein[] = {
     make_bluestein<64, 8, 4>(),    make_bluestein<128, 8, 4>(),   make_bluestein<256, 8, 4>(),
-    // P = 8 up to M = 4096 (two inlined transforms per frame: 16 points per lane
-    // with register twiddles spills even at 256 registers); M = 8192 (N up to
-    // 4096) runs 16 points per lane with the pass-2/3 twiddles in an LDS table.
-    make_bluestein<512, 8, 4>(),   make_bluestein<1024, 8, 2>(),  make_bluestein<2048, 8, 2>(),
-    make_bluestein<4096, 8, 2>(),  make_bluestein<8192, 16, 2, true>(),
+    // P = 8 up to M = 1024; from M = 2048 on, 16 points per lane with the pass-2/3
+    // twiddles in an LDS table (one pass and one exchange less per transform; with
+    // register twiddles two inlined 16-point transforms spill even at 256 VGPRs).
+    // Measured: M = 4096 +24 %, 2048 +6 %, 1024 +-0, 512 -6 %.
+    make_bluestein<512, 8, 4>(),   make_bluestein<1024, 8, 2>(),  make_bluestein<2048, 16, 2, true>(),
+    make_bluestein<4096, 16, 2, true>(),  make_bluestein<8192, 16, 2, true>(),
 };
 const BluesteinVariant* find_bluestein(int M)
 {

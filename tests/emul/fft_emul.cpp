@@ -178,8 +178,8 @@ extern "C" int rpf_emul_bluestein(int N, const float* window, const uint8_t* str
         case 256: return run_bluestein<256, 8>(N, window, stream, nframes, pwr);
         case 512: return run_bluestein<512, 8>(N, window, stream, nframes, pwr);
         case 1024: return run_bluestein<1024, 8>(N, window, stream, nframes, pwr);
-        case 2048: return run_bluestein<2048, 8>(N, window, stream, nframes, pwr);
-        case 4096: return run_bluestein<4096, 8>(N, window, stream, nframes, pwr);
+        case 2048: return run_bluestein<2048, 16>(N, window, stream, nframes, pwr);
+        case 4096: return run_bluestein<4096, 16>(N, window, stream, nframes, pwr);
         case 8192: return run_bluestein<8192, 16>(N, window, stream, nframes, pwr);
     }
     return -1;
