@@ -57,6 +57,12 @@ while time.time() - t0 < budget:
                 assert n == quota, (n, quota)
             host = None
             if buf_len:
+                # two acquisitions on the same engine (a hop after a hop): the first with another
+                # quota and a ragged tail, so carried bytes / staging state must not leak into the second
+                q0 = int(rng.integers(1, quota + 1))
+                cut = min(stream.size, 2 * N * q0 + 2 * int(rng.integers(0, N)))
+                _, done0 = ds.accumulate(stream[:cut], q0)
+                assert done0 == min(q0, cut // (2 * N)), (done0, q0, cut)
                 host, done = ds.accumulate(stream, quota)
                 assert done == quota
     except Exception as ex:
