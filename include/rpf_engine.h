@@ -56,8 +56,10 @@ typedef struct rpf_config {
 #define RPF_FLAG_NONE 0u
 /* Stage raw bytes through VGPRs instead of LDS-DMA (debug / A-B measurement). */
 #define RPF_FLAG_NO_LDS_DMA 1u
-/* Tuning: select kernel variant k (0 = default) for this N; an unknown variant
- * makes rpf_engine_create fail with RPF_ERR_INVALID_ARGUMENT. */
+/* Tuning: select kernel variant k for this N.  The shipped library contains only
+ * variant 0 (one kernel per N x {window} x {staging}); any other k makes
+ * rpf_engine_create fail with RPF_ERR_INVALID_ARGUMENT.  Experimental variants
+ * exist only in the separate -DRPF_TUNING build used by tools/. */
 #define RPF_FLAG_VARIANT(k) (((uint32_t)(k) & 0xffu) << 8)
 
 /* ABI version of the loaded library. */
@@ -112,8 +114,10 @@ int rpf_get_histogram(const rpf_engine* e, int* out /* n_buffers + 1 */);
 int rpf_accumulate(rpf_engine* e, const uint8_t* stream, size_t nbytes, int64_t repeats,
                    double* pwr_out /* N, host */, int64_t* repeats_done);
 
-/* Device-resident replay: the stream already sits in HBM (d_stream, 16-byte
- * aligned).  Enqueues the fused kernel and the partial-sum reduce on
+/* Device-resident replay: the stream already sits in HBM (d_stream: even
+ * address required, else RPF_ERR_INVALID_ARGUMENT; 16-byte aligned for the
+ * LDS-DMA staging path, other alignments silently stage through VGPRs).  The
+ * engine's device is made current for the call and the caller's restored.  Enqueues the fused kernel and the partial-sum reduce on
  * `hip_stream` (a hipStream_t; NULL = HIP's null stream) and returns
  * without synchronising; d_pwr_out[N] (device doubles) is overwritten with the
  * sum over frames [0, min(repeats, nbytes/(2N))).  Used by bench.py and the

@@ -116,6 +116,29 @@ int fail(rpf_engine* e, int rc, const std::string& msg)
     return rc;
 }
 
+// Makes the engine's device current for the scope of an entry point and puts the
+// caller's back afterwards: in a multi-GPU process (one engine per device, or a
+// caller that has another device selected) a launch against engine-owned memory
+// must not depend on -- nor disturb -- the calling thread's current device.
+class DeviceScope {
+public:
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
+        status_ = (prev_ == device) ? hipSuccess : hipSetDevice(device);
+        changed_ = (status_ == hipSuccess && prev_ != device);
+    }
+    ~DeviceScope()
+    {
+        if (changed_ && prev_ >= 0) (void)hipSetDevice(prev_);
+    }
+    hipError_t status() const { return status_; }
+private:
+    int prev_ = -1;
+    bool changed_ = false;
+    hipError_t status_ = hipSuccess;
+};
+
 #define HIP_TRY(e, call)                                                                 \
     do {                                                                                 \
         hipError_t err__ = (call);                                                       \
@@ -180,12 +203,23 @@ int launch_frames(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, doubl
 // Consumer thread: the GPU counterpart of Datastore::fftThread.
 void worker_main(rpf_engine* e)
 {
+    // First failure wins; after it the worker issues no further HIP work and only
+    // keeps the hand-off protocol alive (buffers go straight back to the producer)
+    // until rpf_finish reports the error.
     auto bail = [&](hipError_t err, const char* what) {
+        if (e->worker_rc != RPF_OK) return;
         e->worker_rc = RPF_ERR_HARDWARE;
         e->worker_error = std::string(what) + ": " + hipGetErrorString(err);
     };
-    hipError_t err = hipSetDevice(e->device);
-    if (err != hipSuccess) bail(err, "hipSetDevice");
+    auto ok = [&]() { return e->worker_rc == RPF_OK; };
+#define WORKER_TRY(call, what)                          \
+    do {                                                \
+        if (ok()) {                                     \
+            hipError_t err__ = (call);                  \
+            if (err__ != hipSuccess) bail(err__, what); \
+        }                                               \
+    } while (0)
+    WORKER_TRY(hipSetDevice(e->device), "hipSetDevice");
 
     const size_t frame_bytes = 2 * static_cast<size_t>(e->N);
     size_t carry = 0;             // bytes of an unfinished frame at the end of the previous slot
@@ -200,10 +234,7 @@ void worker_main(rpf_engine* e)
     hipEvent_t copying_done = nullptr;
     auto recycle = [&]() {
         if (copying.empty()) return;
-        if (copying_done) {
-            hipError_t rerr = hipEventSynchronize(copying_done);
-            if (rerr != hipSuccess) bail(rerr, "hipEventSynchronize(copy_done)");
-        }
+        if (copying_done) WORKER_TRY(hipEventSynchronize(copying_done), "hipEventSynchronize(copy_done)");
         std::lock_guard<std::mutex> lk(e->status_mutex);
         for (HostBuffer* b : copying) e->empty_buffers.push_back(b);   // datastore.cxx:91-94
         copying.clear();
@@ -249,8 +280,7 @@ void worker_main(rpf_engine* e)
             StagingSlot& after = e->staging[slot_idx];
             for (StagingSlot* s : {&slot, &after}) {
                 if (!s->in_flight) continue;
-                err = hipEventSynchronize(s->kernel_done);
-                if (err != hipSuccess) bail(err, "hipEventSynchronize(kernel_done)");
+                WORKER_TRY(hipEventSynchronize(s->kernel_done), "hipEventSynchronize(kernel_done)");
                 s->in_flight = false;
             }
             // new bytes go right after the head room; the carried partial frame
@@ -259,19 +289,15 @@ void worker_main(rpf_engine* e)
             size_t off = 0;
             for (HostBuffer* b : group) {
                 if (b->size == 0) continue;
-                err = hipMemcpyAsync(dst + off, b->data, b->size, hipMemcpyHostToDevice, e->copy_stream);
-                if (err != hipSuccess) bail(err, "hipMemcpyAsync(H2D)");
+                WORKER_TRY(hipMemcpyAsync(dst + off, b->data, b->size, hipMemcpyHostToDevice, e->copy_stream),
+                           "hipMemcpyAsync(H2D)");
                 off += b->size;
             }
-            err = hipEventRecord(slot.copy_done, e->copy_stream);
-            if (err != hipSuccess) bail(err, "hipEventRecord(copy_done)");
-            if (carry) {
-                err = hipMemcpyAsync(dst - carry, carry_src, carry, hipMemcpyDeviceToDevice,
-                                     e->compute_stream);
-                if (err != hipSuccess) bail(err, "hipMemcpyAsync(carry)");
-            }
-            err = hipStreamWaitEvent(e->compute_stream, slot.copy_done, 0);
-            if (err != hipSuccess) bail(err, "hipStreamWaitEvent");
+            WORKER_TRY(hipEventRecord(slot.copy_done, e->copy_stream), "hipEventRecord(copy_done)");
+            if (carry)
+                WORKER_TRY(hipMemcpyAsync(dst - carry, carry_src, carry, hipMemcpyDeviceToDevice, e->compute_stream),
+                           "hipMemcpyAsync(carry)");
+            WORKER_TRY(hipStreamWaitEvent(e->compute_stream, slot.copy_done, 0), "hipStreamWaitEvent");
 
             const size_t avail = carry + total;
             int64_t nframes = static_cast<int64_t>(avail / frame_bytes);
@@ -285,9 +311,8 @@ void worker_main(rpf_engine* e)
                 }
                 frames_issued += nframes;
             }
-            err = hipEventRecord(slot.kernel_done, e->compute_stream);
-            if (err != hipSuccess) bail(err, "hipEventRecord(kernel_done)");
-            slot.in_flight = true;
+            WORKER_TRY(hipEventRecord(slot.kernel_done, e->compute_stream), "hipEventRecord(kernel_done)");
+            slot.in_flight = ok();
             // the unfinished frame (if any) stays in this slot until the next group
             const size_t consumed = static_cast<size_t>(nframes) * frame_bytes;
             carry = (frames_issued < e->repeats) ? (avail - consumed) % frame_bytes : 0;
@@ -297,7 +322,7 @@ void worker_main(rpf_engine* e)
             // ours are already queued behind them), this group's one iteration later
             recycle();
             copying = group;
-            copying_done = slot.copy_done;
+            copying_done = ok() ? slot.copy_done : nullptr;
         } else {
             recycle();
             copying = group;          // nothing was copied: returned at the next recycle()
@@ -306,14 +331,11 @@ void worker_main(rpf_engine* e)
     }
     recycle();
 
-    err = hipStreamSynchronize(e->compute_stream);
-    if (err != hipSuccess) bail(err, "hipStreamSynchronize");
+    WORKER_TRY(hipStreamSynchronize(e->compute_stream), "hipStreamSynchronize");
     for (auto& s : e->staging) s.in_flight = false;
-    if (e->worker_rc == RPF_OK) {
-        err = hipMemcpy(e->pwr.data(), e->d_pwr, sizeof(double) * e->N, hipMemcpyDeviceToHost);
-        if (err != hipSuccess) bail(err, "hipMemcpy(pwr)");
-    }
+    WORKER_TRY(hipMemcpy(e->pwr.data(), e->d_pwr, sizeof(double) * e->N, hipMemcpyDeviceToHost), "hipMemcpy(pwr)");
     e->repeats_done = frames_issued;
+#undef WORKER_TRY
 }
 
 void release_device(rpf_engine* e)
@@ -413,7 +435,8 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
                                 std::string(#call) + ": " + hipGetErrorString(err__)));  \
     } while (0)
 
-    CREATE_TRY(hipSetDevice(e->device));
+    DeviceScope on_device(e->device);       // the caller's current device is restored on return
+    CREATE_TRY(on_device.status());
     CREATE_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
     CREATE_TRY(hipStreamCreateWithFlags(&e->compute_stream, hipStreamNonBlocking));
 
@@ -529,8 +552,10 @@ void rpf_engine_destroy(rpf_engine* e)
         int64_t dummy;
         (void)rpf_finish(e, &dummy);
     }
-    (void)hipSetDevice(e->device);
-    release_device(e);
+    {
+        DeviceScope on_device(e->device);
+        release_device(e);
+    }
     delete e;
 }
 
@@ -541,7 +566,8 @@ int rpf_begin(rpf_engine* e, int64_t repeats)
     if (!e) return fail(nullptr, RPF_ERR_INVALID_ARGUMENT, "rpf_begin: NULL engine");
     if (e->worker_running) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_begin: acquisition already running");
     if (repeats < 0) return fail(e, RPF_ERR_INVALID_ARGUMENT, "Argument to 'repeats' must be a positive number.");
-    HIP_TRY(e, hipSetDevice(e->device));
+    DeviceScope on_device(e->device);
+    HIP_TRY(e, on_device.status());
     // acquisition.cxx:252-254
     std::fill(e->pwr.begin(), e->pwr.end(), 0.0);
     HIP_TRY(e, hipMemsetAsync(e->d_pwr, 0, sizeof(double) * e->N, e->compute_stream));
@@ -628,6 +654,10 @@ int rpf_finish(rpf_engine* e, int64_t* repeats_done)
 int rpf_get_power(const rpf_engine* e, double* out)
 {
     if (!e || !out) return RPF_ERR_INVALID_ARGUMENT;
+    // datastore.h:40-47: results are read only after the worker has been joined
+    if (e->worker_running)
+        return fail(const_cast<rpf_engine*>(e), RPF_ERR_INVALID_ARGUMENT,
+                    "rpf_get_power: acquisition still running (call rpf_finish first)");
     std::memcpy(out, e->pwr.data(), sizeof(double) * e->N);
     return RPF_OK;
 }
@@ -680,6 +710,10 @@ int rpf_accumulate_device(rpf_engine* e, const void* d_stream, size_t nbytes, in
     if (e->worker_running)
         return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_accumulate_device: acquisition running");
     if (repeats < 0) return fail(e, RPF_ERR_INVALID_ARGUMENT, "Argument to 'repeats' must be a positive number.");
+    if (reinterpret_cast<uintptr_t>(d_stream) & 1)
+        return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_accumulate_device: d_stream must be at least 2-byte aligned");
+    DeviceScope on_device(e->device);
+    HIP_TRY(e, on_device.status());
     hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the HIP null stream
     int64_t nframes = static_cast<int64_t>(nbytes / (2 * static_cast<size_t>(e->N)));
     nframes = std::min(nframes, repeats);
@@ -697,6 +731,10 @@ int rpf_device_fused(rpf_engine* e, const void* d_stream, size_t nbytes, int64_t
 {
     if (!e || !d_stream) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_fused: NULL argument");
     if (e->worker_running) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_fused: acquisition running");
+    if (reinterpret_cast<uintptr_t>(d_stream) & 1)
+        return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_fused: d_stream must be at least 2-byte aligned");
+    DeviceScope on_device(e->device);
+    HIP_TRY(e, on_device.status());
     int64_t nframes = static_cast<int64_t>(nbytes / (2 * static_cast<size_t>(e->N)));
     nframes = std::min(nframes, repeats);
     if (nframes < 1) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_fused: no whole frame");
@@ -712,6 +750,8 @@ int rpf_device_reduce(rpf_engine* e, double* d_pwr_out, void* hip_stream)
 {
     if (!e || !d_pwr_out) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_reduce: NULL argument");
     if (e->last_slots < 1) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_reduce: nothing to reduce");
+    DeviceScope on_device(e->device);
+    HIP_TRY(e, on_device.status());
     HIP_TRY(e, rpf::launch_reduce(e->d_partial, e->last_slots, e->N, d_pwr_out,
                                   /*accumulate=*/false, static_cast<hipStream_t>(hip_stream),
                                   e->plan.partial_f32, e->bigblu ? static_cast<size_t>(e->blu_M) : 0));

@@ -437,7 +437,11 @@ const Variant kVariants[] = {
     make_variant<2048, 16, 2, 2, false, 0, false, 2, 0, true, false, 512>(0),
     make_variant<4096, 16, 2, 2, false, 0, false, 2, 0, true, false, 512>(0),
     make_variant<8192, 16, 2, 2, false, 0, false, 2>(0),
-    // tuning variants (RPF_FLAG_VARIANT(k)); every one is exact unless it says float32
+#ifdef RPF_TUNING
+    // Lab equipment, compiled only into the -DRPF_TUNING build (make tuning ->
+    // librpf_engine_tuning.so, used by tools/): in the shipped library every N has exactly
+    // one kernel and RPF_FLAG_VARIANT(k != 0) fails rpf_engine_create with
+    // RPF_ERR_INVALID_ARGUMENT.  Every variant is exact unless it says float32 or ablation.
     make_variant<4096, 16, 3, 2, false, 0, false, 2>(1),              // all twiddles in registers
     make_variant<4096, 16, 3, 2, false, 0, false, 1, 0, true>(2),     // one frame ahead only
     make_variant<4096, 16, 2, 2, true, 0, false, 2, 0, true>(3),      // double-buffered slab (one barrier per frame)
@@ -476,6 +480,7 @@ const Variant kVariants[] = {
     make_variant<4096, 16, 2, 2, false, 0, false, 2, 8, true, false, 512>(38),    // no HBM staging
     make_variant<4096, 16, 2, 2, false, 0, false, 2, 13, true, false, 512>(36),   // butterflies only
     make_variant<4096, 16, 2, 2, false, 0, false, 2, 12, true, false, 512>(37),   // butterflies + accumulate only
+#endif  // RPF_TUNING
 };
 
 const Variant* find_variant(int N, int vid)

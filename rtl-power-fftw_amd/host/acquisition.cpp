@@ -16,6 +16,14 @@ Acquisition::Acquisition(const Options& options, AuxData& aux, SampleSource& sou
     : options_(options), aux_(aux), source_(source), data_(data), meta_(meta),
       actual_samplerate_(actual_samplerate), freq_(freq)
 {
+    shard_.repeats = options.repeats;
+}
+
+Acquisition::Acquisition(const Options& options, AuxData& aux, SampleSource& source, Datastore& data,
+                         ScanMetadata& meta, int actual_samplerate, int64_t freq, const Shard& shard)
+    : options_(options), aux_(aux), source_(source), data_(data), meta_(meta),
+      actual_samplerate_(actual_samplerate), freq_(freq), shard_(shard), sharded_(true)
+{
 }
 
 std::string Acquisition::utc_now()
@@ -41,14 +49,19 @@ void Acquisition::run()
     }
     if (!tuned) throw TuneError(freq_);
     if (chatty()) std::cerr << "Device tuned to: " << tuned_freq_ << " Hz" << std::endl;
+    if (sharded_ && !source_.position(shard_.hop_base, 2 * static_cast<uint64_t>(options_.N) *
+                                                          static_cast<uint64_t>(shard_.first_frame)))
+        throw RPFexception("This sample source cannot be split across devices.", ReturnValue::InvalidArgument);
 
-    data_.begin();                                              // :252-256
+    data_.begin(shard_.repeats);                                // :252-256
 
     start_stamp_ = utc_now();
-    std::time(&meta_.scanBeg);
-    if (meta_.cntTimeStamps == 0) {
-        meta_.firstAcqTimestamp = utc_now();
-        meta_.cntTimeStamps++;
+    if (!sharded_) {
+        std::time(&meta_.scanBeg);
+        if (meta_.cntTimeStamps == 0) {
+            meta_.firstAcqTimestamp = utc_now();
+            meta_.cntTimeStamps++;
+        }
     }
     if (chatty()) std::cerr << "Acquisition started at " << start_stamp_ << std::endl;
 
@@ -56,7 +69,7 @@ void Acquisition::run()
     const clock::time_point deadline =
         clock::now() + std::chrono::milliseconds(static_cast<int64_t>(options_.integration_time * 1000));
 
-    const int64_t data_total = 2 * static_cast<int64_t>(options_.N) * options_.repeats;   // :273
+    const int64_t data_total = 2 * static_cast<int64_t>(options_.N) * shard_.repeats;     // :273
     int64_t data_read = 0;
     while (data_read < data_total) {
         Buffer buffer = data_.acquire();                        // :278-285
@@ -70,33 +83,51 @@ void Acquisition::run()
             if (!source_.retry_after_short_read()) break;       // a finite replay has nothing more to give
         } else {
             successful_readouts_++;
-            data_read += wanted;
+            data_read += static_cast<int64_t>(buffer.size());   // == wanted, except for the last read of a replay
             data_.submit(buffer);                               // :320-323
+            if (source_.exhausted()) break;                     // the replay ended inside this buffer
         }
         if (options_.strict_time && clock::now() >= deadline) break;                      // :326-327
         if (interrupts && checkInterrupt(InterruptState::FinishNow)) break;               // :330-331
     }
 
     end_stamp_ = utc_now();
-    std::time(&meta_.scanEnd);
-    meta_.lastAcqTimestamp = utc_now();
-    meta_.sumScanDur += static_cast<float>(std::difftime(meta_.scanEnd, meta_.scanBeg));
-    meta_.avgScanDur = meta_.sumScanDur / meta_.metaRows;
+    if (!sharded_) {
+        std::time(&meta_.scanEnd);
+        meta_.lastAcqTimestamp = utc_now();
+        meta_.sumScanDur += static_cast<float>(std::difftime(meta_.scanEnd, meta_.scanBeg));
+        meta_.avgScanDur = meta_.sumScanDur / meta_.metaRows;
+    }
     if (chatty()) std::cerr << "Acquisition done at " << end_stamp_ << std::endl;
 
     data_.finish();                                             // :343-347
 }
 
+void print_acquisition_summary(int N, int64_t repeats_done, int64_t device_readouts, int64_t successful_readouts,
+                               int actual_samplerate)
+{
+    std::cerr << "Actual number of (complex) samples collected: " << static_cast<int64_t>(N) * repeats_done
+              << std::endl;
+    std::cerr << "Actual number of device readouts: " << device_readouts << std::endl;
+    std::cerr << "Number of successful readouts: " << successful_readouts << std::endl;
+    std::cerr << "Actual number of averaged spectra: " << repeats_done << std::endl;
+    std::cerr << "Effective integration time: " << static_cast<double>(N) * repeats_done / actual_samplerate
+              << " seconds" << std::endl;
+}
+
 void Acquisition::print_summary() const
 {
-    std::cerr << "Actual number of (complex) samples collected: "
-              << static_cast<int64_t>(options_.N) * data_.repeats_done << std::endl;
-    std::cerr << "Actual number of device readouts: " << device_readouts_ << std::endl;
-    std::cerr << "Number of successful readouts: " << successful_readouts_ << std::endl;
-    std::cerr << "Actual number of averaged spectra: " << data_.repeats_done << std::endl;
-    std::cerr << "Effective integration time: "
-              << static_cast<double>(options_.N) * data_.repeats_done / actual_samplerate_ << " seconds"
-              << std::endl;
+    print_acquisition_summary(options_.N, data_.repeats_done, device_readouts_, successful_readouts_,
+                              actual_samplerate_);
+}
+
+void write_text_header(std::ostream& out, const std::string& start_stamp, const std::string& end_stamp)
+{
+    out << "# rtl-power-fftw output" << std::endl;
+    out << "# Acquisition start: " << start_stamp << std::endl;
+    out << "# Acquisition end: " << end_stamp << std::endl;
+    out << "#" << std::endl;
+    out << "# frequency [Hz] power spectral density [dB/Hz]" << std::endl;
 }
 
 namespace {
@@ -147,23 +178,23 @@ void Acquisition::write_data(std::ostream& out) const
 {
     const std::vector<double>* baseline = options_.baseline ? &aux_.baseline_values : nullptr;
     if (!options_.matrixMode) {
-        out << "# rtl-power-fftw output" << std::endl;
-        out << "# Acquisition start: " << start_stamp_ << std::endl;
-        out << "# Acquisition end: " << end_stamp_ << std::endl;
-        out << "#" << std::endl;
-        out << "# frequency [Hz] power spectral density [dB/Hz]" << std::endl;
+        write_text_header(out, start_stamp_, end_stamp_);
         write_spectrum_text(out, data_.pwr, options_.N, data_.repeats_done, tuned_freq_, actual_samplerate_,
                             options_.linear, baseline);
         return;
     }
-    // matrix mode: append one float32 row per acquisition (:385-388,400-409,421-426)
+    append_matrix_row(options_, meta_, data_.pwr, data_.repeats_done, tuned_freq_, actual_samplerate_, baseline);
+}
+
+void append_matrix_row(const Options& options, ScanMetadata& meta, std::vector<double>& pwr, int64_t repeats_done,
+                       int64_t tuned_freq, int samplerate, const std::vector<double>* baseline)
+{
     std::vector<float> row;
-    spectrum_matrix_row(data_.pwr, options_.N, data_.repeats_done, actual_samplerate_, options_.linear,
-                        baseline, row);
-    std::ofstream bin(options_.bin_file, std::ios::out | std::ios::app | std::ios::binary);
+    spectrum_matrix_row(pwr, options.N, repeats_done, samplerate, options.linear, baseline, row);
+    std::ofstream bin(options.bin_file, std::ios::out | std::ios::app | std::ios::binary);
     bin.write(reinterpret_cast<const char*>(row.data()), static_cast<std::streamsize>(row.size() * 4));
-    if (meta_.metaRows == 1) meta_.metaCols += options_.N;
-    if (tuned_freq_ >= options_.finalfreq) meta_.metaRows++;
+    if (meta.metaRows == 1) meta.metaCols += options.N;
+    if (tuned_freq >= options.finalfreq) meta.metaRows++;
 }
 
 }  // namespace rpf_host

@@ -42,17 +42,36 @@ private:
     int64_t freq;
 };
 
+// One device's share of an acquisition in a multi-device scan:
+// `repeats` frames starting `first_frame` frames into the hop whose bytes begin
+// `hop_base` bytes into a sequential replay.
+struct Shard {
+    int64_t repeats = 0;
+    int64_t first_frame = 0;
+    uint64_t hop_base = 0;
+};
+
 class Acquisition {
 public:
     Acquisition(const Options& options, AuxData& aux, SampleSource& source, Datastore& data,
                 ScanMetadata& meta, int actual_samplerate, int64_t freq);
+    // The same for a shard: quiet (the scan's main thread reports in hop order) and
+    // without touching the scan-wide metadata.
+    Acquisition(const Options& options, AuxData& aux, SampleSource& source, Datastore& data,
+                ScanMetadata& meta, int actual_samplerate, int64_t freq, const Shard& shard);
     void run();
     void print_summary() const;
     void write_data(std::ostream& out) const;
 
-private:
-    bool chatty() const { return !options_.talkless || options_.outcnt == 0; }
+    int64_t tuned_freq() const { return tuned_freq_; }
+    const std::string& start_stamp() const { return start_stamp_; }
+    const std::string& end_stamp() const { return end_stamp_; }
+    int64_t device_readouts() const { return device_readouts_; }
+    int64_t successful_readouts() const { return successful_readouts_; }
     static std::string utc_now();
+
+private:
+    bool chatty() const { return !sharded_ && (!options_.talkless || options_.outcnt == 0); }
 
     const Options& options_;
     AuxData& aux_;
@@ -61,11 +80,19 @@ private:
     ScanMetadata& meta_;
     int actual_samplerate_;
     int64_t freq_;
+    Shard shard_;
+    bool sharded_ = false;
     int64_t tuned_freq_ = 0;
     std::string start_stamp_, end_stamp_;
     int64_t device_readouts_ = 0;
     int64_t successful_readouts_ = 0;
 };
+
+// stderr summary of one acquisition (acquisition.cxx:350-358)
+void print_acquisition_summary(int N, int64_t repeats_done, int64_t device_readouts, int64_t successful_readouts,
+                               int actual_samplerate);
+// The five '#' lines that precede a text spectrum (acquisition.cxx:411-419)
+void write_text_header(std::ostream& out, const std::string& start_stamp, const std::string& end_stamp);
 
 // Text/matrix rendering of one accumulated spectrum (acquisition.cxx:377-432).
 // Mutates pwr[N/2] (DC interpolation) exactly like the reference.
@@ -73,6 +100,10 @@ void write_spectrum_text(std::ostream& out, std::vector<double>& pwr, int N, int
                          int64_t tuned_freq, int samplerate, bool linear, const std::vector<double>* baseline);
 void spectrum_matrix_row(std::vector<double>& pwr, int N, int64_t repeats_done, int samplerate, bool linear,
                          const std::vector<double>* baseline, std::vector<float>& row);
+// Matrix mode: append one float32 row to options.bin_file and keep the row/column
+// bookkeeping of the .met file (acquisition.cxx:385-388,400-409,421-426).
+void append_matrix_row(const Options& options, ScanMetadata& meta, std::vector<double>& pwr, int64_t repeats_done,
+                       int64_t tuned_freq, int samplerate, const std::vector<double>* baseline);
 
 }  // namespace rpf_host
 #endif

@@ -75,7 +75,9 @@ public:
   std::vector<double> pwr;           // datastore.h:53 (valid after finish())
 
   // datastore.cxx:23-34
-  Datastore(const Params& params_, std::vector<float>& window_values)
+  // device_override >= 0: HIP device for this instance (one Datastore per device in a
+  // multi-device scan) instead of params.device
+  Datastore(const Params& params_, std::vector<float>& window_values, int device_override = -1)
     : params(params_), pwr(params_.N) {
     if (params.window && (int)window_values.size() != params.N)
       throw RPFexception("Error reading window function. Expected " + std::to_string(params.N)
@@ -87,7 +89,7 @@ public:
     cfg.window = params.window ? window_values.data() : nullptr;
     cfg.n_buffers = params.buffers;
     cfg.buffer_capacity = params.buf_length;
-    cfg.device = params.device;
+    cfg.device = device_override >= 0 ? device_override : params.device;
     cfg.flags = RPF_FLAG_NONE;
     int rc = rpf_engine_create(&cfg, &engine_);
     if (rc != RPF_OK) throw RPFexception(rpf_last_global_error(), (ReturnValue)rc);
@@ -100,7 +102,9 @@ public:
   Datastore& operator=(Datastore&&) = delete;
 
   // acquisition.cxx:252-256: zero pwr, repeats_done = 0, start the worker
-  void begin() { check(rpf_begin(engine_, params.repeats)); repeats_done = 0; }
+  void begin() { begin(params.repeats); }
+  // the same for a shard of an acquisition (multi-device scans: this device's share of the frames)
+  void begin(int64_t repeats) { check(rpf_begin(engine_, repeats)); repeats_done = 0; }
   // acquisition.cxx:278-285
   Buffer acquire() {
     Buffer b;

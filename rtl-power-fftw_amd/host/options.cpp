@@ -1,5 +1,6 @@
 #include "options.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
@@ -53,6 +54,7 @@ const Spec kSpecs[] = {
     {0, "input", Kind::Text, "file|-", "Replay interleaved 8-bit IQ samples from a file or stdin."},
     {0, "synthetic", Kind::Int64, "seed", "Use the built-in synthetic receiver instead of a dongle."},
     {0, "gpu", Kind::Int, "ordinal", "HIP device to run on."},
+    {0, "gpus", Kind::Text, "a,b,...", "HIP devices to spread a scan over (one engine per listed device)."},
     {'h', "help", Kind::Flag, "", "Displays usage information and exits."},
     {0, "version", Kind::Flag, "", "Displays version information and exits."},
 };
@@ -186,6 +188,27 @@ Options parse_command_line(int argc, const char* const* argv)
     o.strict_time = p.has("strict-time");
     if (p.has("overlap")) o.min_overlap = to_number<double>(*find_spec("--overlap"), p.get("overlap"));
     o.device = int_of("gpu", 0);
+    if (p.has("gpus")) {
+        if (p.has("gpu"))
+            throw RPFexception("Options --gpu and --gpus are mutually exclusive. Exiting.", ReturnValue::InvalidArgument);
+        const std::string list = p.get("gpus");
+        size_t pos = 0;
+        while (pos <= list.size()) {
+            const size_t comma = std::min(list.find(',', pos), list.size());
+            const std::string item = list.substr(pos, comma - pos);
+            char* end = nullptr;
+            const long v = std::strtol(item.c_str(), &end, 10);
+            if (item.empty() || *end != '\0' || v < 0 || v > 4095)
+                throw RPFexception("Could not parse the device list given to --gpus: " + list + ".\n"
+                                   "Expecting comma-separated HIP device ordinals. Exiting.",
+                                   ReturnValue::InvalidArgument);
+            o.devices.push_back(static_cast<int>(v));
+            pos = comma + 1;
+        }
+        o.device = o.devices.front();
+    } else {
+        o.devices.push_back(o.device);
+    }
 
     if (o.buf_length % base_buf != 0) {                              // params.cxx:171-175
         o.buf_length = static_cast<int>(std::floor(static_cast<double>(o.buf_length) / base_buf + 0.5) * base_buf);

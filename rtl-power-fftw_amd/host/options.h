@@ -7,11 +7,14 @@
 //   --synthetic <seed>    built-in receiver-like generator
 //   (neither: a live RTL-SDR dongle through librtlsdr, like the reference)
 //   --gpu <ordinal>       HIP device
+//   --gpus <a,b,...>      several HIP devices: the hops of a scan (and, with fewer hops than
+//                         devices, frame ranges of a hop) are dealt to one engine per device
 #ifndef RPF_HOST_OPTIONS_H
 #define RPF_HOST_OPTIONS_H
 
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "datastore.h"
 
@@ -47,6 +50,7 @@ struct Options : Params {
     std::string input_file;          // --input
     bool synthetic = false;          // --synthetic given
     uint64_t synthetic_seed = 2;
+    std::vector<int> devices;        // --gpus a,b,... (else the single --gpu ordinal)
     bool show_help = false, show_version = false;
 };
 

@@ -11,7 +11,7 @@
 
 namespace rpf_host {
 
-FileSource::FileSource(const std::string& path)
+FileSource::FileSource(const std::string& path) : path_(path)
 {
     if (path == "-") {
         file_ = stdin;
@@ -29,8 +29,30 @@ FileSource::~FileSource()
 
 bool FileSource::read(Buffer& buffer)
 {
+    // The last read of a replay is usually short: the producer rounds its request up
+    // to whole 16384-byte transfers (acquisition.cxx:288-300) and the file ends on a
+    // frame.  Those bytes are data, not dropped samples.
     const size_t got = std::fread(buffer.data(), 1, buffer.size(), file_);
-    return got == buffer.size();
+    if (got < buffer.size()) exhausted_ = true;
+    const size_t usable = got & ~static_cast<size_t>(1);
+    if (usable == 0) return false;
+    buffer.resize(usable);
+    return true;
+}
+
+std::unique_ptr<SampleSource> FileSource::clone() const
+{
+    if (!owns_) return nullptr;                  // stdin cannot be read twice
+    std::unique_ptr<SampleSource> copy(new FileSource(path_));
+    copy->set_sample_rate(rate_);
+    return copy;
+}
+
+bool FileSource::position(uint64_t hop_base, uint64_t offset)
+{
+    if (!owns_) return false;
+    exhausted_ = false;
+    return fseeko(file_, static_cast<off_t>(hop_base + offset), SEEK_SET) == 0;
 }
 
 namespace {
@@ -77,6 +99,19 @@ void SyntheticSource::set_frequency(int64_t hz)
     frequency_ = hz;
     seed_ = seed_for(base_seed_, hz);
     position_ = 0;
+}
+
+std::unique_ptr<SampleSource> SyntheticSource::clone() const
+{
+    std::unique_ptr<SampleSource> copy(new SyntheticSource(base_seed_));
+    copy->set_sample_rate(rate_);
+    return copy;
+}
+
+bool SyntheticSource::position(uint64_t, uint64_t offset)
+{
+    position_ = offset / 2;                      // the hop's stream is a function of its frequency alone
+    return true;
 }
 
 bool SyntheticSource::read(Buffer& buffer)

@@ -8,6 +8,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -22,11 +23,23 @@ public:
     virtual int sample_rate() const { return static_cast<int>(rate_); }
     virtual void set_frequency(int64_t hz) { frequency_ = hz; }
     virtual int64_t frequency() const { return frequency_; }
-    // Fill the whole buffer (buffer.size() bytes); false = dropped samples / end of data.
+    // Fill the buffer (buffer.size() bytes); false = dropped samples / nothing read.
+    // A finite replay that hits its end keeps what it got: it shrinks the buffer
+    // to the (even) number of bytes read and returns true while that is non-zero.
     virtual bool read(Buffer& buffer) = 0;
     // After a failed read the reference simply tries again (a dongle keeps
     // streaming, acquisition.cxx:307-316); a finite replay has nothing more to give.
     virtual bool retry_after_short_read() const { return true; }
+    // A finite replay has delivered its last byte: no later acquisition can succeed.
+    virtual bool exhausted() const { return false; }
+    // Multi-device scans: every device reads its own shard through
+    // its own source.  clone() = an independent source over the same data (nullptr:
+    // the source cannot be shared -- one dongle, stdin); position() = make the next
+    // read() return the bytes a single sequential reader would see `offset` bytes
+    // into the hop that starts `hop_base` bytes into the replay (call after
+    // set_frequency; false = not seekable).
+    virtual std::unique_ptr<SampleSource> clone() const { return nullptr; }
+    virtual bool position(uint64_t hop_base, uint64_t offset) { (void)hop_base; (void)offset; return false; }
 protected:
     uint32_t rate_ = 2000000;
     int64_t frequency_ = 0;
@@ -39,9 +52,14 @@ public:
     ~FileSource() override;
     bool read(Buffer& buffer) override;
     bool retry_after_short_read() const override { return false; }
+    bool exhausted() const override { return exhausted_; }
+    std::unique_ptr<SampleSource> clone() const override;
+    bool position(uint64_t hop_base, uint64_t offset) override;
 private:
+    std::string path_;
     std::FILE* file_ = nullptr;
     bool owns_ = false;
+    bool exhausted_ = false;
 };
 
 // The integer-only receiver model of rtl-power-fftw_amd/synth.py (noise_tones_iq):
@@ -54,6 +72,8 @@ public:
     explicit SyntheticSource(uint64_t seed) : base_seed_(seed), seed_(seed) {}
     void set_frequency(int64_t hz) override;
     bool read(Buffer& buffer) override;
+    std::unique_ptr<SampleSource> clone() const override;
+    bool position(uint64_t hop_base, uint64_t offset) override;
     static uint64_t seed_for(uint64_t base, int64_t hz) { return base + static_cast<uint64_t>(hz % 9973); }
     static void generate(uint64_t seed, uint64_t first_sample, uint64_t nsamples, uint8_t* out);
 private:

@@ -11,8 +11,9 @@ it is issued asynchronously and overlapped with the next hop's kernel.
 
 
 def shard_frames(total_frames, world_size, rank):
-    """Contiguous frame range [first, first+count) of `rank`: frame k goes to rank
-    floor(k*G/R), i.e. cuts only at multiples of 2N bytes."""
+    """Contiguous frame range [first, first+count) of `rank`: the cut between rank
+    r-1 and rank r is at frame ceil(total*r/G), so frame k goes to rank
+    floor(k*G/total) and cuts fall only on multiples of 2N bytes."""
     first = (total_frames * rank + world_size - 1) // world_size
     end = (total_frames * (rank + 1) + world_size - 1) // world_size
     return first, end - first

@@ -36,6 +36,13 @@ CASES = [
     ("n16384_r8_uniform", 16384, 8, "uniform", 8, True),           # smallest four-step size, windowed
     ("n5000_r12_uniform", 5000, 12, "uniform", 9, False),          # large Bluestein path, M = 16384
     ("n100000_r3_uniform", 100000, 3, "uniform", 10, False),       # large Bluestein path, M = 262144
+    # BASELINE.json configs[3] on its OWN stream ("as C2, seed 4", tones included), all
+    # 1000 frames: every 64th bin, +-512 bins around the two tone lines, and the total
+    ("c4_n262144_r1000_seed4", 262144, 1000, "noise_tones", 4, False),
+] + [
+    # BASELINE.json configs[4]: 8 hops x 5000 frames of N = 4096, hop h has seed 50 + h;
+    # every hop has its own pwr (acquisition.cxx:252-254), so one full spectrum per hop
+    ("c5_hop%d_n4096_r5000" % h, 4096, 5000, "noise_tones", 50 + h, False) for h in range(8)
 ]
 
 
@@ -45,15 +52,27 @@ def stream_for(gen, seed, nsamples):
     return rpf.synth.noise_tones_iq(seed, nsamples)
 
 
-def truth(N, stream, repeats, window):
-    x = stream[: 2 * N * repeats].astype(np.float32).reshape(repeats, N, 2) - np.float32(127.0)
+def truth(N, stream, repeats, window, chunk_bytes=1 << 28):
+    """datastore.cxx:66-89 in float64, a bounded number of frames at a time."""
     sign = (1 - 2 * (np.arange(N) % 2)).astype(np.float32)
-    x = x * sign[None, :, None]
-    if window is not None:
-        x = x * window[None, :, None]          # float32 product, one rounding
-    z = x[..., 0].astype(np.float64) + 1j * x[..., 1].astype(np.float64)
-    spec = np.fft.fft(z, axis=1)
-    return (spec.real ** 2 + spec.imag ** 2).sum(axis=0)
+    pwr = np.zeros(N)
+    step = max(1, chunk_bytes // (16 * N))
+    for f0 in range(0, repeats, step):
+        f1 = min(repeats, f0 + step)
+        x = stream[2 * N * f0: 2 * N * f1].astype(np.float32).reshape(f1 - f0, N, 2) - np.float32(127.0)
+        x = x * sign[None, :, None]
+        if window is not None:
+            x = x * window[None, :, None]          # float32 product, one rounding
+        z = x[..., 0].astype(np.float64) + 1j * x[..., 1].astype(np.float64)
+        spec = np.fft.fft(z, axis=1)
+        pwr += (spec.real ** 2 + spec.imag ** 2).sum(axis=0)
+    return pwr
+
+
+def tone_bins(N):
+    """Bins of noise_tones_iq's two lines after the (-1)^n centring: the period-8
+    tone (N/8) and the period-16 tone stepped 3 samples at a time (3N/16)."""
+    return [(N // 8 + N // 2) % N, (3 * N // 16 + N // 2) % N]
 
 
 def main():
@@ -73,6 +92,11 @@ def main():
             out["pwr"] = pwr[::64].copy()
             out["stride"] = 64
             out["total"] = pwr.sum()
+            if gen == "noise_tones":
+                # ... and the neighbourhood of the two lines, where a float32 FFT is under most stress
+                near = np.unique(np.concatenate([np.arange(b - 512, b + 513) % N for b in tone_bins(N)]))
+                out["near_bins"] = near.astype(np.int64)
+                out["near_pwr"] = pwr[near].copy()
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         print(name, N, R, "sum %.6e" % pwr.sum())
 

@@ -188,6 +188,17 @@ def golden_stream(g):
     return s
 
 
+# BASELINE.json configs[3] and [4] on their specified streams at full size (tests/golden/make_golden.py)
+C4_CASE = "c4_n262144_r1000_seed4"
+C5_CASES = ["c5_hop%d_n4096_r5000" % h for h in range(8)]
+
+
+def harmonic_bins(N):
+    """Bins where noise_tones_iq's two tones and the harmonics of their integer
+    rounding land: all multiples of N/16 (the (-1)^n shift by N/2 maps the set onto itself)."""
+    return np.arange(16) * (N // 16)
+
+
 GOLDEN_CASES = ["c1_n512_r100_uniform", "n512_r100_hann", "n4096_r64_noise", "n4096_r64_hann",
                 "n64_r33_uniform", "n1024_r17_noise", "n8192_r9_noise", "n500_r20_uniform",
                 "n262144_r2_uniform", "n16384_r8_uniform", "n5000_r12_uniform", "n100000_r3_uniform"]

@@ -59,6 +59,18 @@ def test_invalid_arguments_map_to_reference_exit_codes():
     assert e.value.retval == rpf.ReturnValue.InvalidArgument
 
 
+def test_shipped_library_has_no_tuning_or_ablation_variants():
+    """One kernel per N in the product: the experimental variants (ablations included)
+    exist only in the -DRPF_TUNING build, and RPF_FLAG_VARIANT(k != 0) is an error."""
+    if os.environ.get("RPF_ENGINE_LIB"):
+        pytest.skip("an alternative build is loaded")
+    for n in (512, 1024, 2048, 4096, 8192):
+        for vid in range(1, 64):
+            with pytest.raises(rpf.RPFError) as e:
+                rpf.Datastore(rpf.Params(N=n), flags=(vid << 8))
+            assert e.value.retval == rpf.ReturnValue.InvalidArgument
+
+
 def test_no_device_means_hardware_error_not_a_fallback():
     import torch
     if torch.cuda.is_available():

@@ -81,17 +81,28 @@ def test_device_path_matches_golden_vectors(name, torch_dev):
     assert max_rel(host, got) < 1e-13        # queue path and device path run the same kernels
 
 
-@pytest.mark.parametrize("N,variant", [(4096, 1), (4096, 2), (4096, 3), (4096, 5), (512, 1), (512, 2),
-                                       (512, 3), (1024, 1), (1024, 2), (2048, 1), (2048, 2), (8192, 1)])
-def test_tuning_variants_agree(N, variant, torch_dev):
-    R = 40
-    stream = rpf.synth.uniform_iq(3, N * R)
-    with rpf.Datastore(rpf.Params(N=N, repeats=R)) as a, \
-            rpf.Datastore(rpf.Params(N=N, repeats=R), flags=(variant << 8)) as b:
-        pa, _ = run_device(a, stream, R, torch_dev)
-        pb, _ = run_device(b, stream, R, torch_dev)
-    assert max_rel(pb, pa) < PARITY
-    assert max_rel(pb, truth_f64(N, stream, R)) < VS_TRUTH
+def test_get_power_needs_finish_and_odd_device_pointer_is_rejected(torch_dev):
+    import torch
+    N = 512
+    with rpf.Datastore(rpf.Params(N=N, buf_length=16384, repeats=4)) as ds:
+        ds.begin(4)
+        out = np.zeros(N)
+        rc = ds._lib.rpf_get_power(ds._handle, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        assert rc == int(rpf.ReturnValue.InvalidArgument)          # results are read after the join only
+        assert ds.finish() == 0
+        d_in = torch.zeros(2 * N * 4 + 16, dtype=torch.uint8, device=torch_dev)
+        d_out = torch.zeros(N, dtype=torch.float64, device=torch_dev)
+        with pytest.raises(rpf.RPFError) as e:
+            ds.accumulate_device(d_in.data_ptr() + 1, 2 * N * 4, 4, d_out.data_ptr(), 0)
+        assert e.value.retval == rpf.ReturnValue.InvalidArgument
+        # any even address works (staged through VGPRs when not 16-byte aligned)
+        stream = rpf.synth.uniform_iq(5, N * 4)
+        d_in[2:2 + stream.size] = torch.from_numpy(stream).to(torch_dev)
+        assert ds.accumulate_device(d_in.data_ptr() + 2, stream.size, 4, d_out.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream) == 4
+        torch.cuda.synchronize()
+        want, _ = oracle_accumulate(N, stream, 4)
+        assert max_err_over_mean(d_out.cpu().numpy(), want) < PARITY
 
 
 @pytest.mark.parametrize("N", [2, 6, 30, 32, 100, 500, 1000, 1536, 2046, 3000, 4094])

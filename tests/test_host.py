@@ -215,6 +215,16 @@ def test_cli_exit_codes_without_running_anything(host):
         assert r.returncode == 7 and "no CPU path" in r.stderr              # HardwareError, no fallback
 
 
+def test_cli_gpus_option_is_validated_before_any_device_is_touched(host):
+    assert subprocess.run([CLI, "--gpus", "0,x", "--synthetic", "1"], capture_output=True).returncode == 3
+    assert subprocess.run([CLI, "--gpus", "", "--synthetic", "1"], capture_output=True).returncode in (3, 4)
+    assert subprocess.run([CLI, "--gpu", "0", "--gpus", "0,1", "--synthetic", "1"], capture_output=True).returncode == 3
+    # several devices need a source each device can read on its own: stdin is not one
+    r = subprocess.run([CLI, "-b", "512", "-n", "4", "--input", "-", "--gpus", "0,0"], input=b"\0" * 4096,
+                       capture_output=True)
+    assert r.returncode == 3 and b"needs a source every device can read on its own" in r.stderr
+
+
 # ------------------------------------------------------------------ live dongle (dlopen of librtlsdr)
 FAKE_RTLSDR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rtlsdr", "libfake_rtlsdr.so")
 
@@ -335,3 +345,83 @@ def test_cli_live_dongle_equals_replay_of_the_same_bytes(host, tmp_path):
     assert len(_data_lines(live.stdout)) >= N
     calls = (tmp_path / "calls.log").read_text().split("\n")
     assert "freq 433920000" in calls and calls[-2] == "close"
+
+
+@pytest.mark.gpu
+def test_cli_replay_file_that_ends_on_the_last_frame(host, tmp_path):
+    """A replay file holding exactly 2*N*repeats bytes that is not a multiple of 16384: the
+    producer's last request is rounded up to whole USB transfers (acquisition.cxx:288-300),
+    the read comes back short, and the bytes it did deliver are the tail of the data."""
+    for N, R in ((500, 20), (512, 100), (4096, 3)):
+        stream = rpf.synth.uniform_iq(40 + N, N * R)
+        assert stream.size % 16384 != 0
+        iq = tmp_path / ("iq_%d.u8" % N)
+        iq.write_bytes(stream.tobytes())
+        r = subprocess.run([CLI, "-b", str(N), "-n", str(R), "-f", "1420405752", "--input", str(iq)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "Actual number of averaged spectra: %d" % R in r.stderr and "nan" not in r.stdout.lower()
+        with rpf.Datastore(rpf.Params(N=N, repeats=R)) as ds:
+            pwr, done = ds.accumulate(stream, R)
+        assert done == R
+        buf = ctypes.create_string_buffer(64 * N)
+        oracle_lib().rpf_oracle_format_text(pwr.ctypes.data_as(dp), N, R, 1420405752, 2000000, 0, None, buf, len(buf))
+        assert _data_lines(r.stdout)[:-1] == buf.value.decode().split("\n")[:-1] + [""]
+    # a file with no whole frame at all: no NaN spectrum, AcquisitionError
+    iq = tmp_path / "short.u8"
+    iq.write_bytes(bytes(100))
+    r = subprocess.run([CLI, "-b", "512", "-n", "10", "--input", str(iq)], capture_output=True, text=True)
+    assert r.returncode == 6 and "nan" not in r.stdout.lower()
+    # --continue on a finite replay ends with the data instead of spinning
+    iq = tmp_path / "two.u8"
+    iq.write_bytes(rpf.synth.uniform_iq(9, 512 * 20).tobytes())
+    r = subprocess.run([CLI, "-b", "512", "-n", "10", "--input", str(iq), "-c", "-q"], capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.count("# rtl-power-fftw output") == 2
+
+
+@pytest.mark.gpu
+def test_cli_scan_spread_over_several_engines(host, tmp_path):
+    """--gpus a,b,...: one engine per listed device, hops dealt hop-major, spectra written in
+    hop order.  Two engines on device 0 print byte for byte what one engine
+    prints for the 8-hop scan of config C5's shape (whole hops per engine: the very same
+    sums); three engines cut hops at frame boundaries and their partial sums are added in
+    device order -- equal to the last printed digit."""
+    N, R = 4096, 500
+    scan = ["-f", "100M:116M", "-r", "2000000", "-b", str(N), "-n", str(R), "--synthetic", "50", "-q"]
+    one = subprocess.run([CLI] + scan + ["--gpus", "0"], capture_output=True, text=True)
+    two = subprocess.run([CLI] + scan + ["--gpus", "0,0"], capture_output=True, text=True)
+    three = subprocess.run([CLI] + scan + ["--gpus", "0,0,0"], capture_output=True, text=True)
+    assert one.returncode == 0 and two.returncode == 0 and three.returncode == 0, one.stderr + two.stderr + three.stderr
+    assert one.stdout.count("# rtl-power-fftw output") == 8
+    assert _data_lines(two.stdout) == _data_lines(one.stdout)
+    a, b = _data_lines(one.stdout), _data_lines(three.stdout)
+    assert len(a) == len(b)
+    for la, lb in zip(a, b):
+        if la != lb:                                 # a last-digit difference of the 6-digit dB value
+            fa, fb = la.split(), lb.split()
+            assert fa[0] == fb[0] and abs(float(fa[1]) - float(fb[1])) <= 2e-5 * abs(float(fa[1]))
+    # a single hop over two engines: frame ranges of the one hop, summed
+    single = ["-f", "433920000", "-b", "1024", "-n", "300", "--synthetic", "3", "-q"]
+    s1 = subprocess.run([CLI] + single, capture_output=True, text=True)
+    s2 = subprocess.run([CLI] + single + ["--gpus", "0,0"], capture_output=True, text=True)
+    assert s1.returncode == 0 and s2.returncode == 0, s1.stderr + s2.stderr
+    for la, lb in zip(_data_lines(s1.stdout), _data_lines(s2.stdout)):
+        if la != lb:
+            fa, fb = la.split(), lb.split()
+            assert fa[0] == fb[0] and abs(float(fa[1]) - float(fb[1])) <= 2e-5 * abs(float(fa[1]))
+    # file replay: every engine seeks to its own hops of the one file; matrix rows in hop order
+    hops, n, r = 4, 512, 64
+    stream = rpf.synth.noise_tones_iq(77, hops * 65536 // 2)          # 4 hops x one 65536-byte readout
+    iq = tmp_path / "scan.u8"
+    iq.write_bytes(stream.tobytes())
+    args = ["-f", "100M:108M", "-b", str(n), "-n", str(r), "--input", str(iq), "-q"]
+    f1 = subprocess.run([CLI] + args, capture_output=True, text=True)
+    f2 = subprocess.run([CLI] + args + ["--gpus", "0,0"], capture_output=True, text=True)
+    assert f1.returncode == 0 and f2.returncode == 0, f1.stderr + f2.stderr
+    assert f1.stdout.count("# rtl-power-fftw output") == hops and _data_lines(f1.stdout) == _data_lines(f2.stdout)
+    m1 = subprocess.run([CLI] + args + ["-m", str(tmp_path / "m1")], capture_output=True, text=True)
+    m2 = subprocess.run([CLI] + args + ["-m", str(tmp_path / "m2"), "--gpus", "0,0"], capture_output=True, text=True)
+    assert m1.returncode == 0 and m2.returncode == 0, m1.stderr + m2.stderr
+    assert (tmp_path / "m1.bin").read_bytes() == (tmp_path / "m2.bin").read_bytes()
+    assert (tmp_path / "m1.met").read_text().split("\n")[:5] == (tmp_path / "m2.met").read_text().split("\n")[:5]

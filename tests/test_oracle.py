@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import rtl_power_fftw_amd as rpf
-from helpers import (GOLDEN_CASES, OracleWorker, PlanParams, dp, fp, golden_stream, load_golden,
+from helpers import (C5_CASES, GOLDEN_CASES, OracleWorker, PlanParams, dp, fp, golden_stream, load_golden,
                      max_err_over_mean, max_rel, oracle_accumulate, oracle_lib, truth_f64)
 
 # Tolerances.  float64 oracle vs numpy complex128: pure rounding noise.  float32
@@ -59,6 +59,17 @@ def test_oracle_matches_golden_vectors(name):
     else:
         assert max_rel(p64, g["pwr"]) < TOL64
         check32(p32, g["pwr"], R)
+
+
+@pytest.mark.parametrize("name", [C5_CASES[0], C5_CASES[7]])
+def test_oracle_matches_c5_hop_fixtures(name):
+    """Config C5's hops at full size (5000 frames, seed 50 + hop): first and last hop
+    here, all eight on the GPU box."""
+    g = load_golden(name)
+    N, R = int(g["N"]), int(g["repeats"])
+    p32, done = oracle_accumulate(N, golden_stream(g), R, None, 32)
+    assert done == R
+    assert max_rel(p32, g["pwr"]) < TOL32
 
 
 def test_known_answer_constant_input():
