@@ -4,23 +4,33 @@
 Metric (BASELINE.json): complex IQ samples/s through the fused
 unpack + FFT + |X|^2-accumulate path, inputs resident in HBM.
 
-A "step" is one acquisition of config C2 (N=4096 bins, 10000 repeats,
-rectangular window, synthetic receiver-like u8 IQ): the fused
-kernel K1 over the 81 920 000-byte stream plus the partial-spectrum reduce K3.
-Successive steps walk a ring of distinct replay buffers whose total size exceeds
-the 256 MiB Infinity Cache, so every step reads its bytes from HBM.
+Workloads (--workload, default "auto" = C2 on one GPU, C5 on several):
+  C2  one step = one acquisition, N=4096 bins x 10000 repeats, rectangular window
+      (BASELINE.json's metric configuration; the N=1 headline)
+  C3  the same stream under a periodic Hann window
+  C4  one step = one acquisition, N=262144 bins x 1000 repeats (four-step kernels)
+  C5  one step = one 8-hop scan, N=4096 x 5000 repeats per hop, hop h = seed 50+h.
+      STRONG scaling: the 8 x 5000 frames of a scan are dealt hop-major to the ranks
+      (sharding.shard_hops), every rank runs the fused kernel on its frame ranges and the
+      per-bin accumulators meet in ONE asynchronous RCCL reduce of 8 x 4096 doubles per
+      scan, overlapped with the next scan's kernels.  Rank 0 checks the reduced spectra
+      against the committed float64 fixtures (tests/golden/c5_hop*.npz) before printing.
+With C2/C3/C4 on several GPUs every rank runs its own acquisitions (weak scaling).
 
-N>1 (launched by torch.distributed.run, one rank per GPU): every rank owns an
-independent shard of the frames (weak scaling, per-GPU work fixed) and the
-per-bin accumulators of 8 consecutive steps (the hops of one scan) are summed onto
-rank 0 with ONE asynchronous RCCL reduce of 8 x 4096 doubles that overlaps the
-following steps' kernels.
+Successive steps walk a ring of distinct replay buffers whose total size exceeds the
+256 MiB Infinity Cache, so every step reads its bytes from HBM.
+
+Timing: an untimed pre-warm of >= 0.2 s (clocks, caches, lazy HIP state), then W warm-up
+steps, then EXACTLY K steps between barrier + synchronize; when one such region is shorter
+than 0.5 s it is repeated and the MEDIAN region is reported (regions listed in
+"timing"), so a 20-step run reports what a 2000-step run reports.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes
 import json
+import math
 import os
 import sys
 import time
@@ -30,10 +40,21 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_BINS = 4096
-REPEATS = 10000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector FP32 peak (FMA counted as 2)
+CLOCK_GHZ = 2.4                # peak shader clock used for the issue-slot fractions
+N_CUS = 256
 CPU_BASELINE_SECONDS = 10.0
+PREWARM_SECONDS = 0.2
+MIN_REGION_SECONDS = 0.5
+MAX_REGIONS = 25
+
+WORKLOADS = {
+    "C2": dict(N=4096, R=10000, window=False, seed=2),
+    "C3": dict(N=4096, R=10000, window=True, seed=2),
+    "C4": dict(N=262144, R=1000, window=False, seed=4),
+    "C5": dict(N=4096, R=5000, window=False, seed=50, hops=8),
+}
 
 
 def load_oracle():
@@ -49,61 +70,155 @@ def load_oracle():
     return lib
 
 
-def cpu_baseline(stream, pwr_gpu, window=None):
+def cpu_baseline(N, R, stream, pwr_gpu, window=None):
     """Time the CPU restatement (oracle, kind 'port') on this box's host cores on
-    a bounded sample of the same workload, and check the GPU result against it."""
+    a bounded sample of the same workload, check the GPU result against it, and --
+    if this box has the reference's real FFT provider -- real FFTW next to both."""
     lib = load_oracle()
     u8p = ctypes.POINTER(ctypes.c_uint8)
     dp = ctypes.POINTER(ctypes.c_double)
     wp = window.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if window is not None else None
-    pwr = np.zeros(N_BINS)
+    pwr = np.zeros(N)
     done = ctypes.c_int64()
     passes = 0
     t0 = time.perf_counter()
     while True:
-        rc = lib.rpf_oracle_accumulate(N_BINS, wp, 32, stream.ctypes.data_as(u8p), stream.size,
-                                       REPEATS, pwr.ctypes.data_as(dp), ctypes.byref(done))
-        assert rc == 0 and done.value == REPEATS
+        rc = lib.rpf_oracle_accumulate(N, wp, 32, stream.ctypes.data_as(u8p), stream.size,
+                                       R, pwr.ctypes.data_as(dp), ctypes.byref(done))
+        assert rc == 0 and done.value == R
         passes += 1
         dt = time.perf_counter() - t0
         if dt >= CPU_BASELINE_SECONDS:
             break
-    one = N_BINS * REPEATS * passes / dt
+    one = N * R * passes / dt
     rel = float(np.max(np.abs(pwr_gpu - pwr) / pwr))
     # all host cores (disjoint frame ranges; not the reference's structure)
     cores = os.cpu_count() or 1
-    pwr_mt = np.zeros(N_BINS)
+    pwr_mt = np.zeros(N)
     t0 = time.perf_counter()
     p2 = 0
     while True:
-        rc = lib.rpf_oracle_accumulate_mt(N_BINS, wp, stream.ctypes.data_as(u8p), stream.size,
-                                          REPEATS, cores, pwr_mt.ctypes.data_as(dp), ctypes.byref(done))
+        rc = lib.rpf_oracle_accumulate_mt(N, wp, stream.ctypes.data_as(u8p), stream.size,
+                                          R, cores, pwr_mt.ctypes.data_as(dp), ctypes.byref(done))
         assert rc == 0
         p2 += 1
         dt2 = time.perf_counter() - t0
         if dt2 >= CPU_BASELINE_SECONDS / 2:
             break
-    allc = N_BINS * REPEATS * p2 / dt2
-    return {
+    allc = N * R * p2 / dt2
+    out = {
         "value": one, "unit": "samples/s", "cores": 1, "kind": "port",
-        "sample": "C2 stream (%d frames x %d bins) replayed %d times through oracle/rpf_oracle.c, "
-                  "1 thread like the reference's single FFT thread" % (REPEATS, N_BINS, passes),
+        "sample": "the step's stream (%d frames x %d bins) replayed %d times through oracle/rpf_oracle.c, "
+                  "1 thread like the reference's single FFT thread" % (R, N, passes),
         "all_cores_value": allc, "all_cores": cores,
         "gpu_vs_cpu_max_rel_err": rel,
     }
+    # real FFTW (the reference's FFT, datastore.cxx:30-33,82), if this box has it: first 400 frames
+    try:
+        from oracle import fftw_probe
+        head = min(R, 400)
+        head_bytes = stream[: 2 * N * head]
+        o_head = np.zeros(N)
+        lib.rpf_oracle_accumulate(N, wp, 32, head_bytes.ctypes.data_as(u8p), head_bytes.size, head,
+                                  o_head.ctypes.data_as(dp), ctypes.byref(done))
+        out["fftw"] = fftw_probe.report(N, head_bytes, head, {"oracle": o_head}, window)
+    except Exception as exc:          # the probe must never take the benchmark down
+        out["fftw"] = {"fftw": "probe failed: %r" % (exc,)}
+    return out
+
+
+def end_to_end(rpf, N, R, stream, window, device):
+    """(beta) The same stream through the reference's buffer hand-off: pinned host buffers ->
+    hipMemcpyAsync -> fused kernel, copies overlapped with compute.  `replay`: the producer
+    memcpys the host stream into the pinned buffers (what a file replay does, rpf_accumulate);
+    `resident`: the pinned buffers already hold data (acquire/submit only: engine + PCIe)."""
+    out = []
+    for label, buf_length, buffers in (("reference default: 5 x 1638400 B", 1638400, 5),
+                                       ("one large -s: 5 x 104857600 B", 104857600, 5)):
+        try:
+            with rpf.Datastore(rpf.Params(N=N, window=window is not None, repeats=R, buf_length=buf_length,
+                                          buffers=buffers), window, device=device) as ds:
+                nbytes = 2 * N * R
+                ds.accumulate(stream, R)                                  # warm
+                reps = 3
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    _, done = ds.accumulate(stream, R)
+                t_replay = (time.perf_counter() - t0) / reps
+                assert done == R
+                # pinned buffers filled once (untimed pass), then only handed over (timed pass)
+                total_frames = 4 * R
+                need = 2 * N * total_frames
+
+                def hand_over(fill):
+                    ds.begin(total_frames)
+                    filled = set()
+                    sent = 0
+                    while sent < need:
+                        buf = ds.acquire()
+                        if fill and buf.ctypes.data not in filled:
+                            off = ((len(filled) * buf_length) % max(1, nbytes - buf_length)) & ~1
+                            n0 = min(buf_length, nbytes - off)
+                            buf[:n0] = stream[off:off + n0]
+                            filled.add(buf.ctypes.data)
+                        n = min(buf_length, need - sent)
+                        ds.submit(buf, n)
+                        sent += n
+                    return ds.finish()
+
+                hand_over(True)
+                t0 = time.perf_counter()
+                done = hand_over(False)
+                t_res = time.perf_counter() - t0
+                assert done == total_frames
+            out.append({"buffers": label,
+                        "replay_samples_per_s": N * R / t_replay, "replay_GBps": nbytes / t_replay / 1e9,
+                        "resident_samples_per_s": N * total_frames / t_res,
+                        "resident_pcie_GBps": need / t_res / 1e9})
+        except Exception as exc:
+            out.append({"buffers": label, "error": repr(exc)})
+    return {"what": "pinned host buffers -> hipMemcpyAsync overlapped with the fused kernel (queue path of "
+                    "include/rpf_engine.h); never the headline value. PCIe Gen5 x16 spec 63 GB/s.",
+            "cases": out}
+
+
+def secondary_limits(N, frames_per_launch, kernel_s):
+    """FP32-VALU and LDS fractions of the dominant kernel beside the HBM figure (SURVEY.md 8d:
+    'secondary limiters side by side').  Nominal flops 5 N log2 N per frame; issue-slot
+    figures from the instruction mix of the compiled loop (profiles/isa_mix.json, written by
+    tools/isa_mix.py from the shipped library's disassembly) x the guide's cycles per instruction."""
+    out = {}
+    flops = 5.0 * N * math.log2(N) * frames_per_launch
+    out["fp32_nominal_tflops"] = flops / kernel_s / 1e12
+    out["fp32_nominal_frac_of_valu_peak"] = out["fp32_nominal_tflops"] / FP32_VALU_PEAK_TFLOPS
+    path = os.path.join(ROOT, "profiles", "isa_mix.json")
+    try:
+        mix = json.load(open(path)).get(str(N))
+    except Exception:
+        mix = None
+    if mix:
+        # one loop iteration = mix["frames_per_iteration"] frames on mix["waves"] waves of one workgroup
+        iters = frames_per_launch / mix["frames_per_iteration"]
+        simd_cycles_avail = kernel_s * CLOCK_GHZ * 1e9 * N_CUS * 4
+        lds_cycles_avail = kernel_s * CLOCK_GHZ * 1e9 * N_CUS
+        out["valu_issue_frac"] = mix["valu_cycles_per_wave_iteration"] * mix["waves"] * iters / simd_cycles_avail
+        out["lds_frac"] = mix["lds_cycles_per_wave_iteration"] * mix["waves"] * iters / lds_cycles_avail
+        out["source"] = "profiles/isa_mix.json (%s) x MI355X_MICROARCH.md cycle tables at %.1f GHz" % (
+            mix.get("kernel", "?"), CLOCK_GHZ)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--replay-buffers", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=None, help="default: 2000 (C2/C3), 200 (C5), 100 (C4)")
+    ap.add_argument("--warmup", type=int, default=None, help="default: steps / 20")
+    ap.add_argument("--replay-buffers", type=int, default=0, help="0 = enough to exceed the Infinity Cache")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
-                    help="initialise torch.distributed (RCCL) and run the per-step reduce even with one rank")
-    ap.add_argument("--workload", choices=["C2", "C3"], default="C2",
-                    help="C2 (default, the metric's configuration): rectangular window; C3: periodic Hann window")
+                    help="initialise torch.distributed (RCCL) and run the reduce even with one rank")
+    ap.add_argument("--workload", choices=["auto", "C2", "C3", "C4", "C5"], default="auto")
     ap.add_argument("--event-every", type=int, default=8,
                     help="bracket the fused kernel with HIP events on every k-th timed step")
     args = ap.parse_args()
@@ -128,41 +243,68 @@ def main():
     dev = torch.device("cuda", local_rank if use_dist else 0)
     torch.cuda.set_device(dev)
 
-    # ---- workload: this rank's shard of the frames (seeded per rank) ----------
-    stream_bytes = 2 * N_BINS * REPEATS
-    base = rpf.synth.noise_tones_iq(2 + 1000 * rank, N_BINS * REPEATS)
-    d_base = torch.from_numpy(base).to(dev)
-    nb = max(1, args.replay_buffers)
-    # further replay buffers = the same stream rotated by whole frames (distinct
-    # addresses and byte order, same statistics)
-    bufs = [d_base] + [torch.roll(d_base, shifts=2 * N_BINS * (37 * i)) for i in range(1, nb)]
+    name = args.workload
+    if name == "auto":
+        name = "C2" if world == 1 else "C5"
+    wl = WORKLOADS[name]
+    N, R = wl["N"], wl["R"]
+    strong = name == "C5"
+    hops = wl.get("hops", 1)
+    if args.steps is None:                           # C4/C5 steps are 5-20x longer than C2's
+        args.steps = {"C4": 100, "C5": 200}.get(name, 2000)
+    if args.warmup is None:
+        args.warmup = max(1, args.steps // 20)
 
-    window = rpf.synth.hann_window(N_BINS) if args.workload == "C3" else None
-    ds = rpf.Datastore(rpf.Params(N=N_BINS, window=window is not None, repeats=REPEATS), window,
-                       device=dev.index or 0)
-    # Multi-GPU exchange: the spectra of HOPS consecutive steps (= the
-    # hops of one scan, config C5 has 8) meet in ONE reduce of HOPS*N doubles --
-    # fewer, larger collectives -- issued asynchronously on a ring of blocks so that
-    # it overlaps the following steps' kernels.
-    HOPS = 8
+    # ---- workload ------------------------------------------------------------------------
+    # what this rank processes per step: list of (hop, first_frame, frames)
+    if strong:
+        mine = rpf.sharding.shard_hops(hops, R, world, rank)
+    else:
+        mine = [(0, 0, R)]
+    # the streams, generated on the device (bit-identical to synth.noise_tones_iq)
+    base = []
+    for hop, first, count in mine:
+        seed = wl["seed"] + hop if strong else wl["seed"] + 1000 * rank
+        base.append(rpf.synth.noise_tones_iq_torch(seed, N * count, dev, first=N * first))
+    step_bytes = sum(int(b.numel()) for b in base)
+    nb = args.replay_buffers or max(2, -(-(640 << 20) // max(1, step_bytes)))
+    # further replay buffers = the same frames rotated by whole frames (distinct addresses and byte
+    # order, same statistics, the same sum over frames up to rounding)
+    bufs = [base] + [[torch.roll(b, shifts=2 * N * (37 * i)) for b in base] for i in range(1, nb)]
+
+    window = rpf.synth.hann_window(N) if wl["window"] else None
+    ds = rpf.Datastore(rpf.Params(N=N, window=window is not None, repeats=R), window, device=dev.index or 0)
+    # Exchange: one block = the `hops` spectra of a scan (C5) or of `hops`=8 consecutive
+    # acquisitions (C2-C4), reduced onto rank 0 with ONE async RCCL reduce -- fewer, larger collectives --
+    # on a ring of blocks so that it overlaps the following steps' kernels.
+    rows = hops if strong else 8
     nring = 4
-    d_pwr = [torch.zeros(HOPS, N_BINS, dtype=torch.float64, device=dev) for _ in range(nring)]
+    d_pwr = [torch.zeros(rows, N, dtype=torch.float64, device=dev) for _ in range(nring)]
     s = torch.cuda.current_stream().cuda_stream
     pending = [None] * nring
 
     def step(i, ev=None):
-        blk, hop = (i // HOPS) % nring, i % HOPS
-        if hop == 0 and pending[blk] is not None:
+        if strong:
+            blk = i % nring
+            new_block, last_of_block = True, True
+        else:
+            blk, row = (i // rows) % nring, i % rows
+            new_block, last_of_block = row == 0, row == rows - 1
+        if new_block and pending[blk] is not None:
             pending[blk].wait()
             pending[blk] = None
-        if ev is not None:
-            ev[0].record()
-        ds.device_fused(bufs[i % nb].data_ptr(), stream_bytes, REPEATS, s)
-        if ev is not None:
-            ev[1].record()
-        ds.device_reduce(d_pwr[blk][hop].data_ptr(), s)
-        if use_dist and hop == HOPS - 1:
+        streams = bufs[i % nb]
+        for k, (hop, first, count) in enumerate(mine):
+            out_row = d_pwr[blk][hop if strong else row]
+            if ev is not None and k == 0:
+                ev[0].record()
+            ds.device_fused(streams[k].data_ptr(), 2 * N * count, count, s)
+            if ev is not None and k == 0:
+                ev[1].record()
+            ds.device_reduce(out_row.data_ptr(), s)
+        if use_dist and last_of_block:
             pending[blk] = dist.reduce(d_pwr[blk], dst=0, op=dist.ReduceOp.SUM, async_op=True)
+        return blk
 
     def drain():
         for k in range(nring):
@@ -171,80 +313,170 @@ def main():
                 pending[k] = None
 
     def fence(last_step=None):
-        # a scan cut short by the step count still owes its (partial) reduce
-        if use_dist and last_step is not None and last_step % HOPS != HOPS - 1:
-            blk = (last_step // HOPS) % nring
+        # a block of acquisitions cut short by the step count still owes its (partial) reduce
+        if use_dist and not strong and last_step is not None and last_step % rows != rows - 1:
+            blk = (last_step // rows) % nring
             dist.reduce(d_pwr[blk], dst=0, op=dist.ReduceOp.SUM)
         drain()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # this rank's own spectrum of buffer 0 (checked against the CPU oracle below)
-    d_chk = torch.zeros(N_BINS, dtype=torch.float64, device=dev)
-    ds.accumulate_device(bufs[0].data_ptr(), stream_bytes, REPEATS, d_chk.data_ptr(), s)
+    # this rank's own spectrum of its first shard in replay buffer 0 (checked against the CPU oracle below)
+    d_chk = torch.zeros(N, dtype=torch.float64, device=dev)
+    ds.accumulate_device(base[0].data_ptr(), 2 * N * mine[0][2], mine[0][2], d_chk.data_ptr(), s)
     torch.cuda.synchronize()
     pwr_first = d_chk.cpu().numpy().copy()
 
+    # ---- untimed pre-warm, warm-up, timed regions ----------------------------------------------
+    t0 = time.perf_counter()
+    i = 0
+    while True:
+        step(i)
+        i += 1
+        if i % 4 == 0:
+            torch.cuda.synchronize()
+            flag = torch.tensor([1.0 if time.perf_counter() - t0 < PREWARM_SECONDS else 0.0], device=dev)
+            if use_dist:
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)      # every rank leaves together
+            if flag.item() == 0.0:
+                break
+    prewarm_steps = i
+    fence(None if strong else i - 1)
     for i in range(args.warmup):
         step(i)
     fence(args.warmup - 1 if args.warmup else None)
 
     events = []
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev = None
-        if args.event_every > 0 and i % args.event_every == 0:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            events.append(ev)
-        step(i, ev)
-    fence(args.steps - 1)
-    elapsed = time.perf_counter() - t0
+    regions = []
+    last_blk = 0
+    while True:
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            ev = None
+            if args.event_every > 0 and i % args.event_every == 0 and len(events) < 4096:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                events.append(ev)
+            last_blk = step(i, ev)
+        fence(args.steps - 1)
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        regions.append(elapsed)
+        # repeat short regions (decided on the max-over-ranks time, so every rank agrees)
+        target = min(MAX_REGIONS, max(1, int(math.ceil(MIN_REGION_SECONDS / max(regions[0], 1e-9)))))
+        if len(regions) >= target:
+            break
+    elapsed = float(np.median(regions))
 
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # ---- C5: the reduced spectra of the last scan against the committed fixtures -----------------
+    check = None
+    if strong and rank == 0:
+        got = d_pwr[last_blk].cpu().numpy()
+        worst = 0.0
+        for hop in range(hops):
+            g = np.load(os.path.join(ROOT, "tests", "golden", "c5_hop%d_n4096_r5000.npz" % hop))
+            assert int(g["N"]) == N and int(g["repeats"]) == R and int(g["seed"]) == wl["seed"] + hop
+            worst = max(worst, float(np.max(np.abs(got[hop] - g["pwr"]) / g["pwr"])))
+        check = {"reduced_spectra_vs_float64_fixtures_max_rel": worst, "hops": hops,
+                 "fixtures": "tests/golden/c5_hop*_n4096_r5000.npz"}
+        assert worst < 1e-6, "reduced C5 spectra differ from the fixtures: %g" % worst
+
+    # the same scan on ONE GPU (rank 0 alone, after the measurement): the strong-scaling comparator
+    one_gpu = None
+    if strong and world > 1:
+        if rank == 0:
+            all_hops = [rpf.synth.noise_tones_iq_torch(wl["seed"] + h, N * R, dev) for h in range(hops)]
+            d_one = torch.zeros(hops, N, dtype=torch.float64, device=dev)
+
+            def scan():
+                for h in range(hops):
+                    ds.accumulate_device(all_hops[h].data_ptr(), 2 * N * R, R, d_one[h].data_ptr(), s)
+            for _ in range(20):
+                scan()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nscan = 100
+            for _ in range(nscan):
+                scan()
+            torch.cuda.synchronize()
+            one_gpu = hops * R * N * nscan / (time.perf_counter() - t0)
+            del all_hops
+        dist.barrier()
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
-        value = world * N_BINS * REPEATS * args.steps / elapsed
+        samples_per_step = hops * R * N if strong else world * N * R
+        value = samples_per_step * args.steps / elapsed
         k1_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else None
-        alg_bytes = 2 * N_BINS * REPEATS + 8 * N_BINS + (4 * N_BINS if window is not None else 0)
+        frames_per_launch = mine[0][2]
+        alg_bytes = 2 * N * frames_per_launch + 8 * N + (4 * N if window is not None else 0)
         info = ds.launch_info()
         roof = None
         if k1_ms:
             achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
-            traffic = measured_peak = None
+            traffic = measured_peak = traffic_note = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    traffic = tj.get("fft_accum_%s_hbm_bytes_per_launch" % args.workload.lower())
+                    key = {"C2": "fft_accum_c2", "C3": "fft_accum_c3", "C4": "fourstep_c4", "C5": "fft_accum_c5"}[name]
+                    traffic = tj.get(key + "_hbm_bytes_per_launch")
+                    traffic_note = "%s; captured %s" % (tj.get("source"), tj.get("captured", "round 1 (date not recorded)"))
                     measured_peak = tj.get("measured_read_only_GBps")   # tools/hbm_read_bench.hip, same box type
                 except Exception:
                     traffic = None
+            kernel = ("fft_accum_kernel<N=4096,P=16> (K1)" if N == 4096 else
+                      "fourstep transform of one acquisition (all batches of the column/row kernels)")
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "kernel": "fft_accum_kernel<N=4096,P=16>", "kernel_ms": k1_ms,
-                    "algorithmic_bytes_per_launch": alg_bytes,
-                    "samples_per_s_kernel_only": N_BINS * REPEATS / (k1_ms * 1e-3)}
+                    "traffic_source": ("NOT measured in this run: rocprofv3 PMC capture replayed from profiles/traffic.json -- "
+                                       + str(traffic_note)) if traffic else None,
+                    "kernel": kernel, "kernel_ms": k1_ms, "kernel_ms_samples": len(events),
+                    "algorithmic_bytes_per_launch": alg_bytes, "frames_per_launch": frames_per_launch,
+                    "samples_per_s_kernel_only": N * frames_per_launch / (k1_ms * 1e-3),
+                    # the contracted roofline is HBM read; what actually limits the kernel:
+                    "limited_by": "fp32-valu + lds (see secondary): ~55 flop/B against a machine balance of ~20",
+                    "secondary": secondary_limits(N, frames_per_launch, k1_ms * 1e-3)}
             if measured_peak:
                 roof["measured_read_only_peak"] = measured_peak
                 roof["frac_of_measured_read_only"] = achieved / measured_peak
+        desc = {
+            "C2": "C2: N=4096 bins x 10000 repeats per step per GPU, rectangular window",
+            "C3": "C3: N=4096 bins x 10000 repeats per step per GPU, periodic Hann window",
+            "C4": "C4: N=262144 bins x 1000 repeats per step per GPU, rectangular window",
+            "C5": "C5: 8-hop scan per step, N=4096 bins x 5000 repeats per hop (seed 50+hop), "
+                  "hop-major frame-aligned shards over %d GPU(s)" % world,
+        }[name]
         out = {
             "metric": "IQ samples/s through FFT+|X|^2-accumulate",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: N=4096 bins x 10000 repeats per step per GPU, %s window, " % (
-                args.workload, "periodic Hann" if window is not None else "rectangular") +
-                                   "u8 IQ resident in HBM (%d replay buffers of %d B)" % (nb, stream_bytes),
-                       "launch": info, "reduce": "one async RCCL reduce of 8 x 4096 f64 bins per 8 steps" if use_dist else "none"},
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc + ", u8 IQ resident in HBM (%d replay buffers of %d B per GPU)" % (nb, step_bytes),
+                       "launch": info,
+                       "shards_of_rank0": [list(m) for m in mine] if strong else None,
+                       "reduce": ("one async RCCL reduce of %d x %d f64 bins per %s" % (
+                           rows, N, "scan" if strong else "8 steps")) if use_dist else "none"},
+            "timing": {"prewarm_steps": prewarm_steps, "regions_s": regions, "reported": "median region",
+                       "min_region_s": min(regions), "max_region_s": max(regions)},
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1:       # the CPU leg is timed at N=1 only
-            out["cpu_baseline"] = cpu_baseline(base, pwr_first, window)
+        if check:
+            out["check"] = check
+        if one_gpu:
+            out["one_gpu_same_workload"] = {"value": one_gpu, "unit": "samples/s",
+                                            "what": "the same 8-hop scan on rank 0's GPU alone, no reduce"}
+        if world == 1 and not args.force_dist:
+            # rank 0's first shard on the host for the CPU legs
+            host = base[0].cpu().numpy()
+            fr = mine[0][2]
+            if not args.no_cpu_baseline:       # the CPU leg is timed at N=1 only
+                out["cpu_baseline"] = cpu_baseline(N, fr, host, pwr_first, window)
+            if not args.no_end_to_end and N <= 8192:
+                out["end_to_end"] = end_to_end(rpf, N, fr, host, window, dev.index or 0)
         print(json.dumps(out), flush=True)
 
     ds.close()

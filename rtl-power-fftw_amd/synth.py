@@ -35,24 +35,69 @@ _TONE16_C = np.array([6, 6, 4, 2, 0, -2, -4, -6, -6, -6, -4, -2, 0, 2, 4, 6], dt
 _TONE16_S = np.array([0, 2, 4, 6, 6, 6, 4, 2, 0, -2, -4, -6, -6, -6, -4, -2], dtype=np.int32)
 
 
-def noise_tones_iq(seed, nsamples, chunk=1 << 22):
+def noise_tones_iq(seed, nsamples, chunk=1 << 22, first=0):
     """Receiver-like stream: approximately Gaussian noise (sum of four uniform
     bytes, sigma ~ 20 LSB around 128) plus two weak complex tones (period 8,
     amplitude 10 LSB; period 16 with a 3-sample step, amplitude 6 LSB), clipped
-    to [0,255].  Dynamic range of the spectrum ~1e3 (configs C2-C5)."""
+    to [0,255].  Dynamic range of the spectrum ~1e3 (configs C2-C5).
+    `first`: index of the first complex sample (a shard of the seed's stream)."""
     out = np.empty(2 * nsamples, dtype=np.uint8)
     pos = 0
     while pos < nsamples:
         n = min(chunk, nsamples - pos)
         # one 64-bit word per complex sample: bytes 0-3 -> I noise, 4-7 -> Q noise
-        b = splitmix64(seed, n, offset=pos).view(np.uint8).reshape(n, 8).astype(np.int32)
+        b = splitmix64(seed, n, offset=first + pos).view(np.uint8).reshape(n, 8).astype(np.int32)
         ni = (b[:, 0:4].sum(axis=1) - 510) * 35 // 256
         nq = (b[:, 4:8].sum(axis=1) - 510) * 35 // 256
-        k = np.arange(pos, pos + n, dtype=np.int64)
+        k = np.arange(first + pos, first + pos + n, dtype=np.int64)
         ti = _TONE8_C[k % 8] + _TONE16_C[(3 * k) % 16]
         tq = _TONE8_S[k % 8] + _TONE16_S[(3 * k) % 16]
         out[2 * pos: 2 * (pos + n): 2] = np.clip(128 + ni + ti, 0, 255).astype(np.uint8)
         out[2 * pos + 1: 2 * (pos + n) + 1: 2] = np.clip(128 + nq + tq, 0, 255).astype(np.uint8)
+        pos += n
+    return out
+
+
+def _wrap64(v):
+    """A 64-bit pattern as the signed Python int torch's int64 holds."""
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def noise_tones_iq_torch(seed, nsamples, device, first=0, chunk=1 << 24):
+    """The same bytes as noise_tones_iq(seed, nsamples, first=first), generated on `device`
+    with torch integer arithmetic (int64 with two's-complement wrap-around = the uint64
+    arithmetic of splitmix64; logical right shifts are arithmetic shifts masked).  Used
+    where a 0.5 GB stream would take a minute of numpy: bench.py and the full-size tests
+    (which check it against the committed stream checksums)."""
+    import torch
+    gamma, m1, m2 = (_wrap64(int(c)) for c in (_GAMMA, _M1, _M2))
+
+    def lsr(z, k):
+        return (z >> k) & ((1 << (64 - k)) - 1)
+
+    t8c = torch.tensor(_TONE8_C, dtype=torch.int32, device=device)
+    t8s = torch.tensor(_TONE8_S, dtype=torch.int32, device=device)
+    t16c = torch.tensor(_TONE16_C, dtype=torch.int32, device=device)
+    t16s = torch.tensor(_TONE16_S, dtype=torch.int32, device=device)
+    out = torch.empty(2 * nsamples, dtype=torch.uint8, device=device)
+    pos = 0
+    while pos < nsamples:
+        n = min(chunk, nsamples - pos)
+        k = torch.arange(first + pos, first + pos + n, dtype=torch.int64, device=device)
+        z = (k + 1) * gamma + _wrap64(int(seed))
+        z = (z ^ lsr(z, 30)) * m1
+        z = (z ^ lsr(z, 27)) * m2
+        z = z ^ lsr(z, 31)
+        si = ((z & 0xff) + (lsr(z, 8) & 0xff) + (lsr(z, 16) & 0xff) + (lsr(z, 24) & 0xff)).to(torch.int32)
+        sq = ((lsr(z, 32) & 0xff) + (lsr(z, 40) & 0xff) + (lsr(z, 48) & 0xff) + (lsr(z, 56) & 0xff)).to(torch.int32)
+        ni = ((si - 510) * 35) >> 8                   # floor division by 256
+        nq = ((sq - 510) * 35) >> 8
+        k8, k16 = (k % 8), ((3 * k) % 16)
+        vi = 128 + ni + t8c[k8] + t16c[k16]
+        vq = 128 + nq + t8s[k8] + t16s[k16]
+        out[2 * pos: 2 * (pos + n): 2] = vi.clamp_(0, 255).to(torch.uint8)
+        out[2 * pos + 1: 2 * (pos + n) + 1: 2] = vq.clamp_(0, 255).to(torch.uint8)
         pos += n
     return out
 

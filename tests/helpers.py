@@ -199,6 +199,32 @@ def harmonic_bins(N):
     return np.arange(16) * (N // 16)
 
 
+def golden_stream_device(g, dev):
+    """The fixture's stream generated on the GPU (synth.noise_tones_iq_torch: the 0.5 GB of
+    config C4 in milliseconds instead of a minute of numpy), verified against the fixture's
+    checksum there.  Returns (host copy, device tensor)."""
+    import torch
+
+    import rtl_power_fftw_amd as rpf
+    N, R = int(g["N"]), int(g["repeats"])
+    assert str(g["generator"]) == "noise_tones"
+    d = rpf.synth.noise_tones_iq_torch(int(g["seed"]), N * R, dev)
+    acc = torch.zeros((), dtype=torch.int64, device=dev)
+    step = 1 << 26
+    for p0 in range(0, d.numel(), step):               # xor over bytes[i] * (i + 1), as golden_stream
+        t = d[p0:p0 + step].to(torch.int64) * torch.arange(p0 + 1, p0 + 1 + min(step, d.numel() - p0),
+                                                           dtype=torch.int64, device=dev)
+        while t.numel() > 1:
+            if t.numel() % 2:
+                t = torch.cat([t, torch.zeros(1, dtype=torch.int64, device=dev)])
+            half = t.numel() // 2
+            t = t[:half] ^ t[half:]
+        acc ^= t[0]
+    assert np.uint64(int(acc.item()) & ((1 << 64) - 1)) == g["stream_crc"], \
+        "the torch generator is not reproducing the fixture's bytes"
+    return d.cpu().numpy(), d
+
+
 GOLDEN_CASES = ["c1_n512_r100_uniform", "n512_r100_hann", "n4096_r64_noise", "n4096_r64_hann",
                 "n64_r33_uniform", "n1024_r17_noise", "n8192_r9_noise", "n500_r20_uniform",
                 "n262144_r2_uniform", "n16384_r8_uniform", "n5000_r12_uniform", "n100000_r3_uniform"]

@@ -10,8 +10,8 @@ import numpy as np
 import pytest
 
 import rtl_power_fftw_amd as rpf
-from helpers import (C4_CASE, C5_CASES, ROOT, dp, golden_stream, harmonic_bins, load_golden, max_rel,
-                     oracle_accumulate, oracle_lib, u8p)
+from helpers import (C4_CASE, C5_CASES, ROOT, dp, golden_stream_device, harmonic_bins, load_golden, max_rel,
+                     oracle_lib, u8p)
 
 pytestmark = pytest.mark.gpu
 
@@ -44,9 +44,11 @@ def record(name, **values):
 @pytest.fixture(scope="module")
 def c2():
     import torch
-    stream = rpf.synth.noise_tones_iq(2, N * R)
     dev = torch.device("cuda:0")
-    return stream, torch.from_numpy(stream).to(dev), dev
+    d_in = rpf.synth.noise_tones_iq_torch(2, N * R, dev)       # bit-identical to synth.noise_tones_iq (test_synth.py)
+    stream = d_in.cpu().numpy()
+    assert np.array_equal(stream[: 2 * N * 16], rpf.synth.noise_tones_iq(2, N * 16))
+    return stream, d_in, dev
 
 
 def device_run(ds, d_in, first_frame, frames, dev, n=N):
@@ -104,8 +106,7 @@ def test_c5_eight_hops_match_golden_and_shard_like_multi_gpu():
         for hop in range(hops):
             g = load_golden(C5_CASES[hop])
             assert int(g["N"]) == N and int(g["repeats"]) == per_hop and int(g["seed"]) == 50 + hop
-            stream = golden_stream(g)
-            d_in = torch.from_numpy(stream).to(dev)
+            stream, d_in = golden_stream_device(g, dev)
             d_hops.append(d_in)
             got = device_run(ds, d_in, 0, per_hop, dev)
             whole.append(got)
@@ -126,9 +127,9 @@ def test_c5_eight_hops_match_golden_and_shard_like_multi_gpu():
 def c4():
     import torch
     g = load_golden(C4_CASE)
-    stream = golden_stream(g)                 # noise_tones_iq(4, 262144 * 1000): C4's own stream
     dev = torch.device("cuda:0")
-    return g, stream, torch.from_numpy(stream).to(dev), dev
+    stream, d_in = golden_stream_device(g, dev)        # noise_tones_iq(4, 262144 * 1000): C4's own stream
+    return g, stream, d_in, dev
 
 
 def rocfft_power(d_in, n, frames, dev, chunk=40):

@@ -27,3 +27,15 @@ def test_hann_window():
     w = rpf.synth.hann_window(512)
     assert w.dtype == np.float32 and w[0] == 0 and abs(w[256] - 1) < 1e-7
     assert abs(np.mean(w.astype(np.float64) ** 2) - 0.375) < 1e-6
+
+
+def test_torch_generator_is_bit_identical_to_numpy():
+    """bench.py and the full-size GPU tests generate their streams with torch on the device;
+    same bytes as the numpy generator the fixtures were made with, from any first sample."""
+    import torch  # noqa: F401
+    for seed, n, first in ((2, 100003, 0), (57, 65536, 12345), (4, 1 << 18, 262144 * 999)):
+        a = rpf.synth.noise_tones_iq(seed, n, first=first)
+        b = rpf.synth.noise_tones_iq_torch(seed, n, "cpu", first=first, chunk=70000).numpy()
+        assert np.array_equal(a, b)
+    whole = rpf.synth.noise_tones_iq(9, 50000)
+    assert np.array_equal(whole[2 * 1234: 2 * 1234 + 2000], rpf.synth.noise_tones_iq(9, 1000, first=1234))
