@@ -209,6 +209,10 @@ def secondary_limits(N, frames_per_launch, kernel_s):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON: whatever libraries print there (RCCL's version
+    # banner, for one) goes to stderr instead
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default: 2000 (C2/C3), 200 (C5), 100 (C4)")
@@ -477,7 +481,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(N, fr, host, pwr_first, window)
             if not args.no_end_to_end and N <= 8192:
                 out["end_to_end"] = end_to_end(rpf, N, fr, host, window, dev.index or 0)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
 
     ds.close()
     if use_dist:

@@ -98,8 +98,12 @@ __device__ __forceinline__ void stage_raw(const uint8_t* __restrict__ stream, lo
 // per batch, averaged down over the batches.  PF32: partial spectra leave as
 // float32 (half the flush and K3 traffic; each partial is a sum over ~13 frames
 // and there are hundreds of them, so the rounding averages out to ~1e-9).
+__device__ unsigned int g_cu_tickets[1024];   // SKEW variants: arrival counters per CU (never reset: used modulo)
+
+// SKEW (tuning): workgroups that share a CU start SKEW x 64 cycles apart (by the slot their
+// waves got on the SIMD), so that their VALU and LDS phases interleave instead of colliding.
 template <class G, int WG, int OCC, bool WINDOW, bool DMA, bool DBUF, int ACCB = 0, bool PF32 = false,
-          int RAWD = 2, int ABL = 0, bool TWLDS = false, bool RAWREG = false>
+          int RAWD = 2, int ABL = 0, bool TWLDS = false, bool RAWREG = false, int SKEW = 0>
 __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __restrict__ stream,
                                                             long nframes,
                                                             const cf* __restrict__ twN,
@@ -164,6 +168,22 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
         for (int a = 0; a < P; ++a) acc32[a] = 0.0f;
     }
 
+    if constexpr (SKEW > 0) {
+        // the k-th workgroup to arrive on this CU (ticket from a per-CU counter keyed by
+        // HW_REG_XCC_ID and HW_REG_HW_ID's se/sh/cu fields) starts k x SKEW cycles late
+        constexpr int PER_CU = OCC * 256 / WG;
+        int* const box = reinterpret_cast<int*>(smem);          // the slab is not in use yet
+        if (tid == 0) {
+            const unsigned cu = __builtin_amdgcn_s_getreg((6 << 11) | (8 << 6) | 4);     // HW_ID[14:8]
+            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);   // XCC_ID[3:0]
+            box[0] = static_cast<int>(atomicAdd(&g_cu_tickets[((xcc << 7) | cu) & 1023u], 1u) % PER_CU);
+        }
+        exchange_sync<true>();
+        const int ticket = box[0];
+        exchange_sync<true>();
+#pragma unroll 1
+        for (int k = 0; k < ticket * (SKEW / 512); ++k) __builtin_amdgcn_s_sleep(8);
+    }
     PhaseClock clk;
     clk.start();
     for (int it = 0; fb < nframes; fb += stride, ++it) {
@@ -266,6 +286,127 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
             reinterpret_cast<float*>(partial)[static_cast<size_t>(blockIdx.x) * N + bin] = static_cast<float>(v);
         else
             partial[static_cast<size_t>(blockIdx.x) * N + bin] = v;
+    }
+}
+
+// K1, alternating form (N = 2048 / 4096: several frames per 512-thread workgroup, a frame spans
+// more than one wavefront).  In fft_accum_kernel the frames of a workgroup run in lock-step: every
+// wave is in its butterflies at the same time (the LDS idles) and in its exchange at the same time
+// (the VALUs idle) -- measured, a frame round costs the SUM of its VALU and LDS phases.  Here the
+// frame slots form two groups that run half an iteration apart, swapping roles at each of the two
+// workgroup barriers a frame needs anyway:
+//     half-step h:   group 0: phase (h & 1) of frame h / 2,   group 1: phase ((h - 1) & 1) of frame (h - 1) / 2
+//     phase 0: [|X|^2 of the previous frame] unpack, pass-1 butterflies, pass-1 store
+//     phase 1: pass-2 fetch ... last pass
+// so that on every SIMD one wave's arithmetic runs beside the other wave's LDS traffic and
+// barrier wait.  Same arithmetic per frame as fft_accum_kernel: results are bit-identical.
+template <class G, int WG, int OCC, bool WINDOW, bool DMA, int RAWD = 2, bool TWLDS = true, bool ACC_LATE = true>
+__global__ __launch_bounds__(WG, OCC) void fft_accum_alt_kernel(const uint8_t* __restrict__ stream,
+                                                                long nframes,
+                                                                const cf* __restrict__ twN,
+                                                                const float* __restrict__ window,
+                                                                double* __restrict__ partial)
+{
+    constexpr int P = G::P, T = G::T, N = G::N, NPASS = G::NPASS;
+    constexpr int FPW = WG / T;
+    static_assert(WG % T == 0 && T % 64 == 0 && FPW % 2 == 0, "two groups of whole wavefronts");
+    static_assert(NPASS >= 2 && (NPASS == 2 || G::Lcur(2) <= 64), "only the first exchange crosses wavefronts");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* const slab_base = reinterpret_cast<cf*>(smem);                   // [FPW][LDS_CPX]
+    uint8_t* const raw_base = smem + FPW * G::LDS_CPX * sizeof(cf);      // [WG/64][RAWD][128 P]
+
+    const int tid = threadIdx.x;
+    const int fs = tid / T, t = tid % T;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int grp = ((wave * 64) / T) & 1;                               // wave-uniform
+    constexpr int RAW_SLOT = kRawChunk * P;
+    constexpr int PIECES = P / 8;
+    uint8_t* const wave_raw = raw_base + wave * (RAWD * RAW_SLOT);
+    cf* const slab = slab_base + fs * G::LDS_CPX;
+
+    const long stride = static_cast<long>(gridDim.x) * FPW;
+    const long fb0 = static_cast<long>(blockIdx.x) * FPW;
+    const int iters = fb0 < nframes ? static_cast<int>((nframes - fb0 + stride - 1) / stride) : 0;
+    if (iters > 0) {
+#pragma unroll
+        for (int d = 0; d < RAWD; ++d)
+            stage_raw<G, DMA>(stream, fb0 + d * stride, nframes, wave_raw + d * RAW_SLOT, wave, lane);
+    }
+
+    cf tw[NPASS - 1][P - 1];
+    load_twiddles<G, 1, TWLDS>(t, twN, tw);
+    cf* const twtable = reinterpret_cast<cf*>(raw_base + (WG / 64) * RAWD * RAW_SLOT);
+    if constexpr (TWLDS) {
+        fill_twlds<G, 1>(tid, WG, twN, twtable);
+        exchange_sync<true>();
+    }
+    const float sgn = (t & 1) ? -1.0f : 1.0f;
+    float wsgn[P];
+    if constexpr (WINDOW) {
+#pragma unroll
+        for (int a = 0; a < P; ++a) wsgn[a] = window[t + T * a] * sgn;
+    }
+    double acc[P];
+#pragma unroll
+    for (int a = 0; a < P; ++a) acc[a] = 0.0;
+
+    PhaseClock clk;
+    cf x[P];
+    bool pending = false;        // x holds the spectrum of a frame that has not been accumulated yet
+#pragma unroll 1
+    for (int h = 0; h <= 2 * iters; ++h) {
+        const int hh = h - grp;
+        const int it = hh >> 1;
+        if (hh >= 0 && it < iters) {
+            const long fb = fb0 + it * stride;
+            if ((hh & 1) == 0) {
+                if constexpr (ACC_LATE) {
+                    if (pending) phase_accumulate(x, acc, P);
+                }
+                uint8_t* const ring_slot = wave_raw + (it % RAWD) * RAW_SLOT;
+                if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RAWD - 1) * PIECES) : "memory");
+                exchange_sync<false>();
+                phase_unpack<G, WINDOW>(ring_slot + 2 * lane, sgn, wsgn, x);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slot's reads have returned
+                exchange_sync<false>();
+                stage_raw<G, DMA>(stream, fb + RAWD * stride, nframes, ring_slot, wave, lane);
+                phase_butterfly_twiddle<G>(x, tw[0]);
+                phase_store<G, 1>(t, x, slab);
+            } else {
+                if constexpr (NPASS > 2) middle_passes<G, 2, 0, TWLDS>(t, x, tw, slab, clk, twtable);
+                phase_fetch<G, NPASS>(t, x, slab);
+                phase_last<G>(x);
+                const bool active = (fb + fs) < nframes;
+                if constexpr (ACC_LATE) {
+                    pending = active;
+                } else {
+                    if (active) phase_accumulate(x, acc, P);
+                }
+            }
+        }
+        exchange_sync<true>();       // the two groups swap roles
+    }
+    if constexpr (ACC_LATE) {
+        if (pending) phase_accumulate(x, acc, P);
+    }
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (clamped) prefetches
+
+    exchange_sync<true>();
+    double* const stage = reinterpret_cast<double*>(smem);          // [FPW][N + N/16]
+    constexpr int SN = N + N / 16;
+    static_assert(sizeof(double) * SN <= sizeof(cf) * G::LDS_CPX + 2 * N, "stage fits the LDS");
+#pragma unroll
+    for (int a = 0; a < P; ++a) {
+        const int bin = bin_of<G>(t, a);
+        stage[fs * SN + bin + (bin >> 4)] = acc[a];
+    }
+    exchange_sync<true>();
+    for (int bin = tid; bin < N; bin += WG) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < FPW; ++k) v += stage[k * SN + bin + (bin >> 4)];
+        partial[static_cast<size_t>(blockIdx.x) * N + bin] = v;
     }
 }
 
@@ -410,7 +551,7 @@ struct Variant {
 // must admit (= resident workgroups per CU x WG/256).  vid = tuning variant
 // (0 = the default for this N).
 template <int N, int P, int OCC, int OCCW = OCC, bool DBUF = false, int ACCB = 0, bool PF32 = false,
-          int RAWD = 2, int ABL = 0, bool TWLDS = false, bool RAWREG = false, int WGO = 0>
+          int RAWD = 2, int ABL = 0, bool TWLDS = false, bool RAWREG = false, int WGO = 0, int SKEW = 0>
 Variant make_variant(int vid)
 {
     using G = Geom<N, P>;
@@ -419,10 +560,25 @@ Variant make_variant(int vid)
     constexpr int LDS = FPW * ((DBUF ? 2 : 1) * G::LDS_CPX * (int)sizeof(cf) + RAWD * 2 * N) +
                         (TWLDS ? twlds_entries<G>() * (int)sizeof(cf) : 0);
     return Variant{N, vid, P, WG, FPW, LDS, PF32,
-                   {{fft_accum_kernel<G, WG, OCC, false, false, DBUF, ACCB, PF32, RAWD, ABL, TWLDS, RAWREG>,
-                     fft_accum_kernel<G, WG, OCC, false, true, DBUF, ACCB, PF32, RAWD, ABL, TWLDS, RAWREG>},
-                    {fft_accum_kernel<G, WG, OCCW, true, false, DBUF, ACCB, PF32, RAWD, ABL, TWLDS, RAWREG>,
-                     fft_accum_kernel<G, WG, OCCW, true, true, DBUF, ACCB, PF32, RAWD, ABL, TWLDS, RAWREG>}}};
+                   {{fft_accum_kernel<G, WG, OCC, false, false, DBUF, ACCB, PF32, RAWD, ABL, TWLDS, RAWREG, SKEW>,
+                     fft_accum_kernel<G, WG, OCC, false, true, DBUF, ACCB, PF32, RAWD, ABL, TWLDS, RAWREG, SKEW>},
+                    {fft_accum_kernel<G, WG, OCCW, true, false, DBUF, ACCB, PF32, RAWD, ABL, TWLDS, RAWREG, SKEW>,
+                     fft_accum_kernel<G, WG, OCCW, true, true, DBUF, ACCB, PF32, RAWD, ABL, TWLDS, RAWREG, SKEW>}}};
+}
+
+// the alternating form: WG threads = WG / T frame slots in two groups half an iteration apart
+template <int N, int P, int WG, int OCC, int RAWD = 2, bool TWLDS = true, bool ACC_LATE = true>
+Variant make_alt_variant(int vid)
+{
+    using G = Geom<N, P>;
+    constexpr int FPW = WG / G::T;
+    constexpr int LDS = FPW * (G::LDS_CPX * (int)sizeof(cf) + RAWD * 2 * N) +
+                        (TWLDS ? twlds_entries<G>() * (int)sizeof(cf) : 0);
+    return Variant{N, vid, P, WG, FPW, LDS, false,
+                   {{fft_accum_alt_kernel<G, WG, OCC, false, false, RAWD, TWLDS, ACC_LATE>,
+                     fft_accum_alt_kernel<G, WG, OCC, false, true, RAWD, TWLDS, ACC_LATE>},
+                    {fft_accum_alt_kernel<G, WG, OCC, true, false, RAWD, TWLDS, ACC_LATE>,
+                     fft_accum_alt_kernel<G, WG, OCC, true, true, RAWD, TWLDS, ACC_LATE>}}};
 }
 
 const Variant kVariants[] = {
@@ -463,6 +619,21 @@ const Variant kVariants[] = {
     make_variant<2048, 16, 3, 2, false, 0, false, 2, 0, true>(9),
     make_variant<512, 8, 2, 2, false, 0, false, 2, 0, false, false, 512>(9),
     make_variant<8192, 16, 2, 2, false, 0, false, 2, 0, true>(1),
+    // round 2: de-phasing experiments
+    make_alt_variant<4096, 16, 512, 2>(40),                    // alternating groups, |X|^2 deferred into phase 0
+    make_alt_variant<4096, 16, 512, 2, 2, true, false>(41),    // alternating groups, |X|^2 at the end of phase 1
+    make_alt_variant<4096, 16, 512, 2, 1>(42),                 // ... raw ring of one frame
+    make_alt_variant<2048, 16, 512, 2>(40),
+    make_alt_variant<2048, 16, 512, 2, 2, true, false>(41),
+    make_alt_variant<1024, 16, 512, 2>(40),                    // (T = 64: one wavefront per frame, 8 slots)
+    // independent 256-thread workgroups, the k-th on a CU started k x SKEW cycles late
+    make_variant<4096, 16, 3, 2, false, 0, false, 2, 0, true, false, 0, 1536>(43),
+    make_variant<4096, 16, 3, 2, false, 0, false, 2, 0, true, false, 0, 2560>(44),
+    make_variant<4096, 16, 3, 2, false, 0, false, 2, 0, true, false, 0, 3584>(45),
+    make_variant<4096, 16, 2, 2, false, 0, false, 2, 0, true, false, 0, 2560>(46),
+    make_variant<4096, 16, 2, 2, false, 0, false, 2, 0, true, false, 0, 4096>(47),
+    make_variant<4096, 16, 3, 2, false, 0, false, 2, 0, true, false, 0, 512>(48),
+    make_variant<4096, 16, 3, 2, false, 0, false, 1, 0, true, false, 0, 2560>(49),     // raw ring of one frame
     // measurement-only ablations of the default N=4096 kernel (results are garbage)
     make_variant<4096, 16, 3, 2, false, 0, false, 2, 1, true>(11),    // no accumulate
     make_variant<4096, 16, 3, 2, false, 0, false, 2, 2, true>(12),    // no butterfly arithmetic

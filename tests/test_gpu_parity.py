@@ -295,3 +295,25 @@ def test_rocfft_cross_check(torch_dev):
     spec = torch.fft.fft(z, dim=1)
     want = (spec.real.double() ** 2 + spec.imag.double() ** 2).sum(0).cpu().numpy()
     assert max_rel(got, want) < PARITY
+
+
+def test_real_fftw_if_this_box_has_it(torch_dev):
+    """north_star: the averaged spectrum matches the reference FFTW/CPU path within 1e-6 per
+    bin.  FFTW itself exists on few boxes; when it does (dlopen of libfftw3f.so.3, never
+    linked) C1 and the first 400 frames of C2 go through the reference's loop around the real
+    fftwf_execute -- FFTW_MEASURE as the reference plans, and FFTW_ESTIMATE -- and the GPU
+    must be within the bar of both."""
+    import sys
+    from helpers import ROOT
+    sys.path.insert(0, ROOT)
+    from oracle import fftw_probe
+    if fftw_probe.load() is None:
+        pytest.skip("libfftw3f is not installed on this box (\"fftw\": \"absent\"): parity stays unpinned here")
+    for N, R, stream in ((512, 100, rpf.synth.uniform_iq(1, 512 * 100)),
+                         (4096, 400, rpf.synth.noise_tones_iq(2, 4096 * 400))):
+        with rpf.Datastore(rpf.Params(N=N, repeats=R)) as ds:
+            got, _ = run_device(ds, stream, R, torch_dev)
+        rep = fftw_probe.report(N, stream, R, {"gpu": got, "oracle": oracle_accumulate(N, stream, R)[0]})
+        print("real FFTW, N=%d R=%d: %s" % (N, R, rep))
+        for flag in ("measure", "estimate"):
+            assert rep[flag]["max_rel_vs_gpu"] < PARITY and rep[flag]["max_rel_vs_oracle"] < PARITY

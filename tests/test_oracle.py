@@ -282,3 +282,23 @@ def test_producer_read_sizes():
     assert dn(81920000, 0, 1638400) == 1638400
     assert dn(81920000, 81920000 - 1000, 1638400) == 16384
     assert dn(100, 0, 16384) == 16384
+
+
+def test_fftw_probe_pins_the_oracle_when_the_real_library_exists():
+    """The reference's FFT is FFTW3f (datastore.cxx:30-33,82), absent from the build image.
+    Where a box has libfftw3f.so.3 the probe (oracle/fftw_probe.py, dlopen only) runs the
+    reference's loop around the real fftwf_execute and the oracle must agree with it to the
+    parity bar on config C1 and on the head of C2; where it does not, the probe says so."""
+    import sys
+    sys.path.insert(0, __import__("helpers").ROOT)
+    from oracle import fftw_probe
+    c1 = rpf.synth.uniform_iq(1, 512 * 100)
+    rep = fftw_probe.report(512, c1, 100, {"oracle": oracle_accumulate(512, c1, 100)[0]})
+    if fftw_probe.load() is None:
+        assert rep == {"fftw": "absent"}
+        pytest.skip("libfftw3f is not installed here: parity stays unpinned on this box")
+    c2 = rpf.synth.noise_tones_iq(2, 4096 * 400)
+    rep2 = fftw_probe.report(4096, c2, 400, {"oracle": oracle_accumulate(4096, c2, 400)[0]})
+    for r in (rep, rep2):
+        for flag in ("measure", "estimate"):
+            assert r[flag]["max_rel_vs_oracle"] < 1e-6, r
