@@ -56,6 +56,12 @@ typedef struct rpf_config {
 #define RPF_FLAG_NONE 0u
 /* Stage raw bytes through VGPRs instead of LDS-DMA (debug / A-B measurement). */
 #define RPF_FLAG_NO_LDS_DMA 1u
+/* Sizes 16384..262144: use the fused persistent four-step kernel (the intermediate stays in the
+ * XCDs' L2, teams of workgroups synchronised through per-XCD counters) instead of the two-kernel
+ * path (intermediate through HBM).  Exact and parity-tested, but measured SLOWER than the
+ * two-kernel path so far, hence opt-in; the engine falls back by itself where the
+ * kernel's teams cannot assemble. */
+#define RPF_FLAG_FOURSTEP_FUSED 2u
 /* Tuning: select kernel variant k for this N.  The shipped library contains only
  * variant 0 (one kernel per N x {window} x {staging}); any other k makes
  * rpf_engine_create fail with RPF_ERR_INVALID_ARGUMENT.  Experimental variants

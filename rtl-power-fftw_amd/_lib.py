@@ -44,6 +44,7 @@ class rpf_config(ctypes.Structure):
 
 
 FLAG_NO_LDS_DMA = 1
+FLAG_FOURSTEP_FUSED = 2
 
 # every symbol include/rpf_engine.h declares: (name, restype, argtypes)
 _P = ctypes.c_void_p

@@ -85,6 +85,8 @@ struct rpf_engine {
     hipStream_t copy_stream = nullptr, compute_stream = nullptr;
     rpf::cf* d_twiddles = nullptr;
     bool fourstep = false;                // N handled by rpf_fourstep.hip
+    bool fused = false;                   // ... by the fused persistent kernel (Y stays in the XCDs' L2)
+    void* d_fused_ctl = nullptr;          // its team counters / abort flag
     bool bluestein = false;               // N handled by the Bluestein kernel (chirp tables below)
     bool bigblu = false;                  // N handled by the large (four-step) Bluestein path
     int blu_M = 0;                        // bigblu: convolution length (partial spectra have M entries)
@@ -153,6 +155,15 @@ int launch_transform(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, hi
                      int* nslots)
 {
     const uintptr_t addr = reinterpret_cast<uintptr_t>(d_frames);
+    if (e->fourstep && e->fused) {
+        const bool dma = e->use_dma && (addr % 4) == 0;
+        HIP_TRY(e, rpf::launch_fourstep_fused(e->N, e->has_window, dma, d_frames, nframes, e->d_tw_sub, e->d_tw_sub2,
+                                              e->d_twiddles, e->d_window, e->d_scratch, e->d_partial,
+                                              e->d_fused_ctl, stream));
+        e->last = e->plan;
+        *nslots = rpf::fourstep_fused_slots(e->N);
+        return RPF_OK;
+    }
     if (e->fourstep) {
         const bool dma = e->use_dma && (addr % 4) == 0;
         HIP_TRY(e, rpf::launch_fourstep(e->N, e->has_window, dma, d_frames, nframes, e->d_tw_sub,
@@ -197,6 +208,8 @@ int launch_frames(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, doubl
     e->last_slots = nslots;
     HIP_TRY(e, rpf::launch_reduce(e->d_partial, nslots, e->N, d_out, accumulate, stream,
                                   e->plan.partial_f32, e->bigblu ? static_cast<size_t>(e->blu_M) : 0));
+    // a fused launch whose teams did not assemble must not leave something that looks like a spectrum
+    if (e->fused) HIP_TRY(e, rpf::launch_fused_poison(e->d_fused_ctl, d_out, e->N, stream));
     return RPF_OK;
 }
 
@@ -344,6 +357,7 @@ void release_device(rpf_engine* e)
     if (e->d_tw_sub) (void)hipFree(e->d_tw_sub);
     if (e->d_tw_sub2) (void)hipFree(e->d_tw_sub2);
     if (e->d_scratch) (void)hipFree(e->d_scratch);
+    if (e->d_fused_ctl) (void)hipFree(e->d_fused_ctl);
     if (e->d_step2) (void)hipFree(e->d_step2);
     if (e->d_chirp) (void)hipFree(e->d_chirp);
     if (e->d_bhat) (void)hipFree(e->d_bhat);
@@ -499,8 +513,20 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         rpf::make_twiddles(n2, tws);
         CREATE_TRY(hipMalloc(&e->d_tw_sub2, sizeof(rpf::cf) * tws.size()));
         CREATE_TRY(hipMemcpy(e->d_tw_sub2, tws.data(), sizeof(rpf::cf) * tws.size(), hipMemcpyHostToDevice));
-        CREATE_TRY(hipMalloc(&e->d_scratch, rpf::fourstep_scratch_bytes(e->N)));
-        partial_slots = rpf::fourstep_partial_slots(e->N);
+        // The fused kernel (one persistent launch, the intermediate stays in each XCD's L2) where
+        // the device is the 8 x 32-CU part it is written for and its teams assemble; else K2a/K2b.
+        int fused_grid = 0;
+        if ((cfg->flags & RPF_FLAG_FOURSTEP_FUSED) &&
+            rpf::fourstep_fused_prepare(e->N, e->device, &fused_grid) == hipSuccess) {
+            CREATE_TRY(hipMalloc(&e->d_scratch, rpf::fourstep_fused_scratch_bytes(e->N)));
+            CREATE_TRY(hipMalloc(&e->d_fused_ctl, rpf::fourstep_fused_ctl_bytes()));
+            e->fused = true;
+            partial_slots = rpf::fourstep_fused_slots(e->N);
+        } else {
+            (void)hipGetLastError();
+            CREATE_TRY(hipMalloc(&e->d_scratch, rpf::fourstep_scratch_bytes(e->N)));
+            partial_slots = rpf::fourstep_partial_slots(e->N);
+        }
         // K2a reads the inter-step twiddles and the window in its own lane order
         std::vector<rpf::cf> step_tw;
         std::vector<float> window_t;
@@ -518,6 +544,31 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
     CREATE_TRY(hipMalloc(&e->d_partial, sizeof(double) * partial_len * partial_slots));
     CREATE_TRY(hipMalloc(&e->d_pwr, sizeof(double) * e->N));
     CREATE_TRY(hipMemset(e->d_pwr, 0, sizeof(double) * e->N));
+    if (e->fused) {
+        // Prove once that the eight teams assemble on this device (one round per team on a dummy
+        // stream); if they do not, this engine uses the two-kernel path.
+        const size_t round_bytes = 2u * 262144u * 8u;         // FR frames of N samples for each of 8 teams
+        void* d_dummy = nullptr;
+        CREATE_TRY(hipMalloc(&d_dummy, round_bytes));
+        CREATE_TRY(hipMemset(d_dummy, 0x80, round_bytes));
+        bool aborted = true;
+        hipError_t lerr = rpf::launch_fourstep_fused(e->N, e->has_window, true, static_cast<const uint8_t*>(d_dummy),
+                                                     static_cast<long>(round_bytes / (2u * static_cast<size_t>(e->N))),
+                                                     e->d_tw_sub, e->d_tw_sub2, e->d_twiddles, e->d_window, e->d_scratch,
+                                                     e->d_partial, e->d_fused_ctl, e->compute_stream);
+        if (lerr == hipSuccess) lerr = rpf::fourstep_fused_aborted(e->d_fused_ctl, e->compute_stream, &aborted);
+        (void)hipFree(d_dummy);
+        if (lerr != hipSuccess || aborted) {
+            (void)hipGetLastError();
+            e->fused = false;
+            (void)hipFree(e->d_scratch);
+            e->d_scratch = nullptr;
+            (void)hipFree(e->d_partial);
+            e->d_partial = nullptr;
+            CREATE_TRY(hipMalloc(&e->d_scratch, rpf::fourstep_scratch_bytes(e->N)));
+            CREATE_TRY(hipMalloc(&e->d_partial, sizeof(double) * e->N * std::max<size_t>(partial_slots, rpf::fourstep_partial_slots(e->N))));
+        }
+    }
 
     // buffer pool: pinned host memory (datastore.cxx:27-28)
     e->pool.resize(e->n_buffers);
@@ -755,6 +806,7 @@ int rpf_device_reduce(rpf_engine* e, double* d_pwr_out, void* hip_stream)
     HIP_TRY(e, rpf::launch_reduce(e->d_partial, e->last_slots, e->N, d_pwr_out,
                                   /*accumulate=*/false, static_cast<hipStream_t>(hip_stream),
                                   e->plan.partial_f32, e->bigblu ? static_cast<size_t>(e->blu_M) : 0));
+    if (e->fused) HIP_TRY(e, rpf::launch_fused_poison(e->d_fused_ctl, d_pwr_out, e->N, static_cast<hipStream_t>(hip_stream)));
     return RPF_OK;
 }
 

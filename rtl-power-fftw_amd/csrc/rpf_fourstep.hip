@@ -247,6 +247,320 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_rows_kernel(const cf* __restr
 }
 
 
+// ---- fused four-step: the intermediate never leaves the XCD's L2 ----------------------------
+// K2a/K2b above exchange Y through HBM: 8 B written + 8 B read per sample against 2 algorithmic
+// bytes, and the pair runs at the speed of that traffic.  Here ONE persistent kernel does both
+// steps and the exchange stays on chip: the workgroups that share an XCD (one per CU, found by
+// HW_REG_XCC_ID, so correctness never rests on a block -> XCD guess) form a team that owns a round
+// of FR = 262144 / N frames at a time -- N * FR * 8 B = 2 MB of Y, half the XCD's 4 MB L2:
+//     phase A  every member transforms one tile of 16 * SUBA columns and parks the twiddled result
+//              in LDS; once the team has finished READING the previous round's Y (barrier 2) it
+//              writes its rows of Y with plain stores -- the lines stay dirty in the team's L2;
+//     barrier 1 (team-wide: one arrival counter per XCD, relaxed agent-scope polls)
+//     phase B  every member loads one tile of 16 * SUBB rows with sc1 loads (served by the L2, never
+//              by this CU's L1, which other CUs' stores do not refresh), transforms and accumulates.
+// Same-L2 producers and consumers need no release/acquire fences (no buffer_wbl2 / buffer_inv):
+// a store is in the L2 once vmcnt says so, and the L2 is the point of coherence inside an XCD.
+// Every spin is bounded; a team that does not assemble (a CU busy with someone else's kernel, an
+// unexpected XCD population) raises ctl->abort, everybody leaves, and K3 poisons the spectrum with
+// NaN -- loud, never wrong.  The engine proves the path once at creation and otherwise keeps K2a/K2b.
+struct FusedCtl {
+    unsigned arrivals[8][32];     // [xcd][0]: members registered (own 128-byte line each)
+    unsigned barrier[8][32];      // [xcd][0]: monotonically increasing arrival count
+    unsigned registered[32];      // [0]: workgroups registered, grid-wide
+    unsigned abort[32];           // [0]: != 0 -> results invalid
+};
+constexpr unsigned kSpinLimit = 4u << 20;      // polls of ~0.1 us: ~0.5 s
+
+__device__ __forceinline__ unsigned ctl_load(const unsigned* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Team barrier in two halves.  arrive: every thread's global stores are in the L2 (vmcnt) and
+// its loads have returned before thread 0 counts the workgroup in.  wait: thread 0 polls the
+// team's counter (bounded), everybody else parks at the workgroup barrier.
+__device__ __forceinline__ void team_arrive(FusedCtl* ctl, int xcd)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_add(&ctl->barrier[xcd][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool team_wait(FusedCtl* ctl, int xcd, unsigned target, int* ok_flag)
+{
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        int ok = 1;
+        while (ctl_load(&ctl->barrier[xcd][0]) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit || ctl_load(&ctl->abort[0]) != 0) {
+                __hip_atomic_store(&ctl->abort[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        *ok_flag = ok;
+    }
+    __syncthreads();
+    const bool ok = *ok_flag != 0;
+    __syncthreads();            // ok_flag may be rewritten by the next wait
+    return ok;
+}
+
+// -DRPF_FUSED_PROFILE: thread 0 of every workgroup adds the cycles it spends in each segment of a
+// round to g_fused_prof (tools/gpu_fused_profile.py prints them); never in the shipped library.
+#ifdef RPF_FUSED_PROFILE
+__device__ unsigned long long g_fused_prof[10];
+struct FusedClock {
+    unsigned long long last, sum[10];
+    __device__ __forceinline__ void start() { for (int i = 0; i < 10; ++i) sum[i] = 0; last = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void stamp(int i) { const unsigned long long now = __builtin_readcyclecounter(); sum[i] += now - last; last = now; }
+    __device__ __forceinline__ void publish() { if (threadIdx.x == 0) { for (int i = 0; i < 9; ++i) atomicAdd(&g_fused_prof[i], sum[i]); atomicAdd(&g_fused_prof[9], 1ull); } }
+};
+#define FSTAMP(i) fclk.stamp(i)
+#else
+struct FusedClock {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void publish() {}
+};
+#define FSTAMP(i) ((void)0)
+#endif
+
+template <class S, bool WINDOW, bool DMA>
+__global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* __restrict__ stream, int nframes,
+                                                               const cf* __restrict__ tw_n1,
+                                                               const cf* __restrict__ tw_n2,
+                                                               const cf* __restrict__ twN,
+                                                               const float* __restrict__ window,
+                                                               cf* __restrict__ Yall, double* __restrict__ partial,
+                                                               FusedCtl* __restrict__ ctl)
+{
+    using GA = typename S::GA;
+    using GB = typename S::GB;
+    constexpr int N1 = S::N1, N2 = S::N2, N = S::N;
+    constexpr int TA = GA::T, TB = GB::T, P = 8;
+    constexpr int TPF = N / 8192;                   // tiles per frame (both phases)
+    constexpr int FR = 32 / TPF;                    // frames per round
+    constexpr int COLS = 16 * S::SUBA;              // columns per phase-A tile
+    constexpr int PITCH = COLS / 2 + 1;             // dwords per staged raw row (odd: conflict-free column reads)
+    static_assert(TPF >= 1 && TPF <= 32 && N2 / COLS == TPF && N1 / S::ROW_TILE == TPF, "tile counts");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int SLAB_CPX = (S::SLAB_A > S::SLAB_B ? S::SLAB_A : S::SLAB_B);
+    cf* const slabs = reinterpret_cast<cf*>(smem);                                     // [16][SLAB_CPX]
+    unsigned char* const area = smem + kWaves * SLAB_CPX * sizeof(cf);                 // raw rows | Y tile
+    uint8_t* const raw = area;                                                         // [N1][PITCH] dwords
+    cf* const tile = reinterpret_cast<cf*>(area);                                      // [N2][ROW_PITCH]
+    __shared__ int team[4];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- team assembly -------------------------------------------------------------------------
+    if (tid == 0) {
+        const int xcd = static_cast<int>(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20)) & 7;   // XCC_ID[3:0]
+        const unsigned rank = __hip_atomic_fetch_add(&ctl->arrivals[xcd][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&ctl->registered[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        int ok = 1;
+        while (ctl_load(&ctl->registered[0]) < gridDim.x) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > kSpinLimit) { ok = 0; break; }
+        }
+        // the static frame -> team map needs eight equal teams of 32
+        for (int x = 0; ok && x < 8; ++x)
+            if (ctl_load(&ctl->arrivals[x][0]) != 32u) ok = 0;
+        if (!ok) __hip_atomic_store(&ctl->abort[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        team[0] = xcd;
+        team[1] = static_cast<int>(rank);
+        team[2] = ok;
+    }
+    __syncthreads();
+    const int xcd = team[0], rank = team[1];
+    if (!team[2] || rank >= 32) return;
+    const int fsl = rank / TPF, tl = rank % TPF;            // frame slot of the round, tile of the frame
+    cf* const Y = Yall + static_cast<size_t>(xcd) * FR * N + static_cast<size_t>(fsl) * N;
+
+    // Per-lane constants are re-derived at the top of every round from an opaque copy of the thread
+    // index: hoisted out of the loop they (and every address built from them) would stay live across
+    // both phases and spill at 128 VGPRs.  The sub-transform twiddles are re-read from their
+    // L2-resident tables per phase for the same reason, and the f64 accumulators are parked in LDS
+    // outside phase B: behind the raw rows (free while phase A runs, part of the Y tile in phase B).
+    {
+        double* const park0 = reinterpret_cast<double*>(area + ((N1 * PITCH * 4 + 15) / 16) * 16) + tid;
+#pragma unroll
+        for (int a = 0; a < P; ++a) park0[a * kWG] = 0.0;
+    }
+
+    const int nrounds = (nframes + FR - 1) / FR;
+    FusedClock fclk;
+    fclk.start();
+    unsigned bar = 0;                                        // team barriers passed so far
+#pragma unroll 1
+    for (int r = xcd; r < nrounds; r += 8) {
+        const int f = r * FR + fsl;
+        const bool valid = f < nframes;
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));
+        const int lane = tid_ & 63;
+        const int subA = lane / TA, tA = lane % TA, subB = lane / TB, tB = lane % TB;
+        cf* const slabA = slabs + wave * SLAB_CPX + subA * GA::LDS_CPX;
+        cf* const slabB = slabs + wave * SLAB_CPX + subB * GB::LDS_CPX;
+        const int cl = wave * S::SUBA + subA;                   // this lane group's column inside the tile
+        const int c = COLS * tl + cl;                           // n2
+        const float sgn = (c & 1) ? -1.0f : 1.0f;               // (-1)^n, n = N2 n1 + n2
+        const float off = -(kTwo23 + 127.0f) * sgn;
+        const int jrow = wave * S::SUBB + subB;                 // this lane group's row inside the tile
+        double* const park = reinterpret_cast<double*>(area + ((N1 * PITCH * 4 + 15) / 16) * 16) + tid_;
+        // ---- phase A: columns of tile tl -> LDS slabs (natural k1 order) ------------------------
+        if (valid) {
+            const uint8_t* const frame = stream + static_cast<size_t>(f) * (2 * N);
+#pragma unroll 1
+            for (int i = 0; i < (N1 * PITCH + kWG - 1) / kWG; ++i) {
+                const int L = i * kWG + tid_;
+                const int rr = L / PITCH, d = L % PITCH;
+                if (L < N1 * PITCH && d < COLS / 2) {
+                    const uint8_t* src = frame + 2 * (static_cast<size_t>(N2) * rr + COLS * tl) + 4 * d;
+                    if constexpr (DMA) {
+                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(raw + 4 * (i * kWG + wave * 64)), 4, 0, 0);
+                    } else {
+                        const uint16_t lo = *reinterpret_cast<const uint16_t*>(src);
+                        const uint16_t hi = *reinterpret_cast<const uint16_t*>(src + 2);
+                        *reinterpret_cast<uint32_t*>(raw + 4 * L) = lo | (static_cast<uint32_t>(hi) << 16);
+                    }
+                }
+            }
+            if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        FSTAMP(0);                       // raw rows staged
+        if (valid) {
+            cf twA[GA::NPASS - 1][P - 1];
+            load_twiddles<GA, 1>(tA, tw_n1, twA);
+            cf x[P];
+#pragma unroll
+            for (int a = 0; a < P; ++a) {
+                const int n1 = tA + TA * a;
+                const uint32_t iq =
+                    *reinterpret_cast<const uint16_t*>(raw + 4 * (n1 * PITCH + (cl >> 1)) + 2 * (cl & 1));
+                const cf v = iq_plus_2p23(iq);
+                if constexpr (WINDOW) {
+                    const float w = window[static_cast<size_t>(c) * N1 + n1] * sgn;
+                    x[a] = (v - (kTwo23 + 127.0f)) * w;
+                } else {
+                    x[a] = v * sgn + off;
+                }
+            }
+            group_fft<GA>(tA, x, twA, slabA);
+            exchange_sync<false>();
+#pragma unroll
+            for (int a = 0; a < P; ++a) {
+                const int k1 = bin_of<GA>(tA, a);
+                slabA[GA::slot(k1)] = cmul(x[a], twN[static_cast<size_t>(c) * N1 + TA * a + tA]);
+            }
+            exchange_sync<false>();
+        }
+        // ---- wait: the team has finished READING the previous round's Y (arrivals posted after
+        // each member's tile load below); trivially true in the first round ------------------------
+        FSTAMP(1);                       // column transforms
+        if (bar > 0 && !team_wait(ctl, xcd, bar * 32u, &team[3])) return;
+        FSTAMP(2);                       // wait: previous Y read by everybody
+        if (valid) {
+            cf* const yrow = Y + static_cast<size_t>(c) * N1;
+#pragma unroll
+            for (int a = 0; a < P; ++a) yrow[tA + TA * a] = slabA[GA::slot(tA + TA * a)];
+        }
+        // ---- barrier 1: the round's Y is complete in the team's L2 --------------------------------
+        team_arrive(ctl, xcd);
+        FSTAMP(3);                       // Y rows written (stores drained)
+        if (!team_wait(ctl, xcd, ++bar * 32u, &team[3])) return;
+        FSTAMP(4);                       // barrier 1
+        // ---- phase B: rows of tile tl ---------------------------------------------------------------
+        double acc[P];
+#pragma unroll
+        for (int a = 0; a < P; ++a) acc[a] = park[a * kWG];
+        __syncthreads();                // ... before the tile overwrites the parking area
+        if (valid) {
+            const cf* const yt = Y + S::ROW_TILE * tl;
+#pragma unroll
+            for (int i = 0; i < N2 * S::ROW_TILE / kWG; ++i) {
+                const int idx = i * kWG + tid_;
+                const int n2 = idx / S::ROW_TILE, j = idx % S::ROW_TILE;
+                // sc1: served by the L2, bypassing this CU's L1 (other CUs wrote these lines)
+                const unsigned long long bits = __hip_atomic_load(
+                    reinterpret_cast<const unsigned long long*>(yt + static_cast<size_t>(n2) * N1 + j),
+                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tile[n2 * S::ROW_PITCH + j] = __builtin_bit_cast(cf, bits);
+            }
+        }
+        team_arrive(ctl, xcd);          // this member is done with Y (its tile is in LDS)
+        ++bar;
+        FSTAMP(5);                       // Y tile loaded
+        if (valid) {
+            cf twB[GB::NPASS - 1][P - 1];
+            load_twiddles<GB, 1>(tB, tw_n2, twB);
+            cf x[P];
+#pragma unroll
+            for (int a = 0; a < P; ++a) x[a] = tile[(tB + TB * a) * S::ROW_PITCH + jrow];
+            group_fft<GB>(tB, x, twB, slabB);
+            phase_accumulate(x, acc, P);
+            exchange_sync<false>();
+        }
+        __syncthreads();        // tile/slabs are reused by the next round's phase A
+#pragma unroll
+        for (int a = 0; a < P; ++a) park[a * kWG] = acc[a];
+        FSTAMP(6);                       // row transforms + accumulate
+    }
+    fclk.publish();
+
+    // ---- partial spectrum of (team, frame slot): rows of tile tl ---------------------------------------
+    __syncthreads();
+    const int lane = tid & 63;
+    const int subB = lane / TB, tB = lane % TB;
+    const int jrow = wave * S::SUBB + subB;
+    double* const park = reinterpret_cast<double*>(area + ((N1 * PITCH * 4 + 15) / 16) * 16) + tid;
+    double acc[P];
+#pragma unroll
+    for (int a = 0; a < P; ++a) acc[a] = park[a * kWG];
+    __syncthreads();
+    double* const stage = reinterpret_cast<double*>(smem);                          // [N2 k2][ROW_PITCH]
+#pragma unroll
+    for (int a = 0; a < P; ++a) stage[bin_of<GB>(tB, a) * S::ROW_PITCH + jrow] = acc[a];
+    __syncthreads();
+    double* const out = partial + (static_cast<size_t>(xcd) * FR + fsl) * N + S::ROW_TILE * tl;
+#pragma unroll
+    for (int i = 0; i < N2 * S::ROW_TILE / kWG; ++i) {
+        const int idx = i * kWG + tid;
+        const int k2 = idx / S::ROW_TILE, j = idx % S::ROW_TILE;
+        out[static_cast<size_t>(k2) * N1 + j] = stage[k2 * S::ROW_PITCH + j];
+    }
+}
+
+// K3 companion: if the fused kernel gave up, the spectrum must not look like one.
+__global__ void fused_poison_kernel(const FusedCtl* __restrict__ ctl, double* __restrict__ out, int N)
+{
+    if (ctl->abort[0] == 0) return;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
+        out[i] = __builtin_nan("");
+}
+
+#ifdef RPF_FUSED_PROFILE
+}  // namespace
+}  // namespace rpf
+extern "C" int rpf_debug_fused_profile(unsigned long long* out10, int reset)
+{
+    if (hipMemcpyFromSymbol(out10, HIP_SYMBOL(rpf::g_fused_prof), sizeof(unsigned long long) * 10) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[10] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(rpf::g_fused_prof), z, sizeof z);
+    }
+    return 0;
+}
+namespace rpf {
+namespace {
+#endif
+
 // Large Bluestein path: even N in (4096, 131072] that is not a power of two,
 // M = M1 x M2 = 2^ceil(log2(2N-1)) (bluestein_tables.h has the identity):
 //   K2a (BLU)  a = (v - 127) g zero-padded to M; columns of FFT_M #1 -> Y[f][n2][k1]
@@ -352,6 +666,7 @@ using ColsFn = void (*)(const uint8_t*, int, const cf*, const cf*, const float*,
 using MidFn = void (*)(const cf*, int, const cf*, const cf*, const cf*, cf*);
 using RowsFn = void (*)(const cf*, int, const cf*, double*, int);
 
+using FusedFn = void (*)(const uint8_t*, int, const cf*, const cf*, const cf*, const float*, cf*, double*, FusedCtl*);
 using RowsTableFn = void (*)(const cf*, size_t, size_t, int, std::vector<cf>&);
 using ColsTableFn = void (*)(const cf*, int, std::vector<cf>&);
 
@@ -360,7 +675,18 @@ struct SplitInfo {
     ColsFn cols[2][2];   // [window][dma]
     RowsFn rows;
     RowsTableFn step_twiddles;   // W_N^{n2 k1} in K2a's lane order
+    FusedFn fused[2][2];         // [window][dma]
+    int fused_lds, fused_fr;     // LDS bytes; frames per team round
 };
+
+template <class S>
+constexpr int fused_lds_bytes()
+{
+    constexpr int slab = (S::SLAB_A > S::SLAB_B ? S::SLAB_A : S::SLAB_B) * kWaves * (int)sizeof(cf);
+    constexpr int raw = (S::N1 * (16 * S::SUBA / 2 + 1) * 4 + 15) / 16 * 16 + kWG * 8 * (int)sizeof(double);   // + parked accumulators
+    constexpr int tile = S::N2 * S::ROW_PITCH * (int)sizeof(cf);
+    return slab + (raw > tile ? raw : tile);
+}
 
 template <int N1, int N2>
 SplitInfo make_split()
@@ -369,7 +695,10 @@ SplitInfo make_split()
     return SplitInfo{S::N, N1, N2, S::COLS_LDS, S::ROWS_LDS, S::BATCH, S::GROUPS, S::ROW_TILES,
                      {{fourstep_cols_kernel<S, false, false>, fourstep_cols_kernel<S, false, true>},
                       {fourstep_cols_kernel<S, true, false>, fourstep_cols_kernel<S, true, true>}},
-                     fourstep_rows_kernel<S>, lane_ordered_rows<typename S::GA>};
+                     fourstep_rows_kernel<S>, lane_ordered_rows<typename S::GA>,
+                     {{fourstep_fused_kernel<S, false, false>, fourstep_fused_kernel<S, false, true>},
+                      {fourstep_fused_kernel<S, true, false>, fourstep_fused_kernel<S, true, true>}},
+                     fused_lds_bytes<S>(), 262144 / S::N};
 }
 
 const SplitInfo kSplits[] = {
@@ -513,6 +842,77 @@ hipError_t launch_fourstep(int N, bool window, bool use_dma, const uint8_t* d_st
         if (err != hipSuccess) return err;
         first = false;
     }
+    return hipSuccess;
+}
+
+// ---- fused four-step -----------------------------------------------------------
+size_t fourstep_fused_scratch_bytes(int N)       // Y of one round per XCD: 8 x 2 MB
+{
+    const SplitInfo* s = find_split(N);
+    return s ? sizeof(cf) * static_cast<size_t>(s->N) * s->fused_fr * 8 : 0;
+}
+int fourstep_fused_slots(int N)
+{
+    const SplitInfo* s = find_split(N);
+    return s ? 8 * s->fused_fr : 0;
+}
+size_t fourstep_fused_ctl_bytes() { return sizeof(FusedCtl); }
+
+hipError_t fourstep_fused_prepare(int N, int device, int* grid)
+{
+    const SplitInfo* s = find_split(N);
+    if (!s) return hipErrorInvalidValue;
+    if (s->fused_lds > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t err;
+    for (int w = 0; w < 2; ++w)
+        for (int d = 0; d < 2; ++d) {
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(s->fused[w][d]),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, s->fused_lds);
+            if (err != hipSuccess) return err;
+        }
+    hipDeviceProp_t prop;
+    if ((err = hipGetDeviceProperties(&prop, device)) != hipSuccess) return err;
+    // eight teams of 32: one workgroup per CU on a 256-CU, 8-XCD part, all of them resident
+    if (prop.multiProcessorCount != 256) return hipErrorInvalidValue;
+    int per_cu = 0;
+    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(s->fused[0][1]), kWG,
+                                                       s->fused_lds);
+    if (err != hipSuccess) return err;
+    if (per_cu < 1) return hipErrorInvalidValue;
+    *grid = 256;
+    return hipSuccess;
+}
+
+// Frames [0, nframes) -> d_partial[8 * FR][N] (overwritten).  d_ctl: fourstep_fused_ctl_bytes() of
+// device memory; d_scratch: fourstep_fused_scratch_bytes(N).  Follow K3 with launch_fused_poison.
+hipError_t launch_fourstep_fused(int N, bool window, bool use_dma, const uint8_t* d_stream, long nframes,
+                                 const cf* d_tw_n1, const cf* d_tw_n2, const cf* d_twN, const float* d_window,
+                                 cf* d_scratch, double* d_partial, void* d_ctl, hipStream_t stream)
+{
+    const SplitInfo* s = find_split(N);
+    if (!s || nframes < 1 || nframes > 0x7fffffffL) return hipErrorInvalidValue;
+    hipError_t err = hipMemsetAsync(d_ctl, 0, sizeof(FusedCtl), stream);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(s->fused[window ? 1 : 0][use_dma ? 1 : 0], dim3(256), dim3(kWG), s->fused_lds, stream, d_stream,
+                       static_cast<int>(nframes), d_tw_n1, d_tw_n2, d_twN, d_window, d_scratch, d_partial,
+                       static_cast<FusedCtl*>(d_ctl));
+    return hipGetLastError();
+}
+
+hipError_t launch_fused_poison(const void* d_ctl, double* d_out, int N, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fused_poison_kernel, dim3(64), dim3(256), 0, stream, static_cast<const FusedCtl*>(d_ctl), d_out, N);
+    return hipGetLastError();
+}
+
+// Did the last fused launch give up?  (Synchronises with the stream.)
+hipError_t fourstep_fused_aborted(const void* d_ctl, hipStream_t stream, bool* aborted)
+{
+    FusedCtl h;
+    hipError_t err = hipMemcpyAsync(&h, d_ctl, sizeof h, hipMemcpyDeviceToHost, stream);
+    if (err != hipSuccess) return err;
+    if ((err = hipStreamSynchronize(stream)) != hipSuccess) return err;
+    *aborted = h.abort[0] != 0;
     return hipSuccess;
 }
 

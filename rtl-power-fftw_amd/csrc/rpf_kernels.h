@@ -64,6 +64,19 @@ hipError_t launch_fourstep(int N, bool window, bool use_dma, const uint8_t* d_st
                            const cf* d_tw_n1, const cf* d_tw_n2, const cf* d_twN, const float* d_window,
                            cf* d_scratch, double* d_partial, int max_grid, hipStream_t stream);
 
+// ---- fused four-step (rpf_fourstep.hip): one persistent kernel, Y stays in each XCD's L2 --------
+size_t fourstep_fused_scratch_bytes(int N);   // 16 MB: one 2 MB round of Y per XCD
+int fourstep_fused_slots(int N);              // partial spectra written: 8 teams x frames per round
+size_t fourstep_fused_ctl_bytes();
+// fails (hipErrorInvalidValue) unless the device has 256 CUs and one workgroup fits a CU
+hipError_t fourstep_fused_prepare(int N, int device, int* grid);
+hipError_t launch_fourstep_fused(int N, bool window, bool use_dma, const uint8_t* d_stream, long nframes,
+                                 const cf* d_tw_n1, const cf* d_tw_n2, const cf* d_twN, const float* d_window,
+                                 cf* d_scratch, double* d_partial, void* d_ctl, hipStream_t stream);
+// after K3: NaN-fills d_out if the fused kernel raised its abort flag (team did not assemble)
+hipError_t launch_fused_poison(const void* d_ctl, double* d_out, int N, hipStream_t stream);
+hipError_t fourstep_fused_aborted(const void* d_ctl, hipStream_t stream, bool* aborted);
+
 // ---- large Bluestein path (rpf_fourstep.hip): even N in (4096, 131072], not a power of two --
 bool bigblu_supported(int N);
 int bigblu_lengths(int N, int* M, int* m1, int* m2);   // M = m1 * m2 = 2^ceil(log2(2N-1))

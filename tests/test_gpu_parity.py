@@ -146,6 +146,33 @@ def test_four_step_sizes_match_oracle(N, torch_dev):
         assert max_rel(got, truth_f64(N, stream, R, w)) < VS_TRUTH * 1.5   # up to 18 butterfly stages
 
 
+@pytest.mark.parametrize("N", [16384, 32768, 65536, 131072, 262144])
+def test_fused_four_step_equals_the_two_kernel_path(N, torch_dev):
+    """The fused persistent kernel (intermediate kept in the XCDs' L2, teams synchronised through
+    per-XCD counters) against the two-kernel path (intermediate through HBM): same arithmetic per
+    frame, only the grouping of the f64 partial sums differs.  Frame counts that leave teams and
+    frame slots idle, several launches back to back on one engine (stale L2 lines, counters)."""
+    import torch
+    R = 3 * (262144 // N) * 8 + 5                    # a few full rounds and a ragged tail
+    stream = rpf.synth.uniform_iq(17 + N % 31, N * R)
+    d_in = torch.from_numpy(stream).to(torch_dev)
+    w = rpf.synth.hann_window(N) + np.float32(0.25)
+    for window in (None, w):
+        with rpf.Datastore(rpf.Params(N=N, window=window is not None, repeats=R), window,
+                           flags=rpf._lib.FLAG_FOURSTEP_FUSED) as fused, \
+                rpf.Datastore(rpf.Params(N=N, window=window is not None, repeats=R), window) as plain:
+            for frames in (R, 1, 262144 // N, 8 * (262144 // N) + 1, R):
+                outs = []
+                for ds in (fused, plain):
+                    d_out = torch.full((N,), float("nan"), dtype=torch.float64, device=torch_dev)
+                    assert ds.accumulate_device(d_in.data_ptr(), 2 * N * frames, frames, d_out.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream) == frames
+                    torch.cuda.synchronize()
+                    outs.append(d_out.cpu().numpy())
+                assert np.all(np.isfinite(outs[0]))
+                assert max_rel(outs[0], outs[1]) < 1e-12, (N, frames)
+
+
 @pytest.mark.parametrize("N", [4098, 5000, 10000, 16386, 20000, 50000, 100000, 131070])
 def test_large_non_power_of_two_sizes_match_oracle(N, torch_dev):
     """Even N in (4096, 131072] that is not a power of two: Bluestein through the
