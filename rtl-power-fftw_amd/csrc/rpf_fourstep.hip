@@ -38,6 +38,8 @@ namespace rpf {
 
 namespace {
 
+struct __attribute__((aligned(16))) cf4 { cf lo, hi; };   // two neighbouring complex values = one 16-byte access
+
 constexpr int kWG = 1024, kWaves = kWG / 64;
 constexpr int kColTile = 64;          // columns per K2a tile (128 raw bytes per row)
 constexpr int kRowDwords = 33;        // 32 data dwords + 1 pad per staged raw row
@@ -163,9 +165,17 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_cols_kernel(const uint8_t* __
                 slab[G::slot(k1)] = cmul(x[a], twN[static_cast<size_t>(c) * N1 + T * a + t]);
             }
             exchange_sync<false>();
+            // 16 bytes per lane and store: 8-byte stores are issue-bound at ~7 B/clk/CU
+            // (MI355X_MICROARCH.md, store tail), which is what K2a ran at
             cf* const yrow = Y + (static_cast<size_t>(f) * N2 + c) * N1;
 #pragma unroll
-            for (int a = 0; a < G::P; ++a) yrow[t + T * a] = slab[G::slot(t + T * a)];
+            for (int a = 0; a < G::P / 2; ++a) {
+                const int e = 2 * t + 2 * T * a;
+                cf4 v;
+                v.lo = slab[G::slot(e)];
+                v.hi = slab[G::slot(e + 1)];
+                *reinterpret_cast<cf4*>(yrow + e) = v;
+            }
             exchange_sync<false>();
         }
     }
@@ -199,14 +209,15 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_rows_kernel(const cf* __restr
     // The next frame's tile is fetched into registers while this one is transformed
     // (one 1024-thread workgroup per CU: nothing else would overlap the two; a second
     // tile in flight needs 16 more VGPRs than the 128 available -- measured: spills, slower).
-    constexpr int PER = N2 * S::ROW_TILE / kWG;
-    cf nxt[PER];
+    constexpr int PER = N2 * S::ROW_TILE / kWG / 2;      // 16-byte loads: two neighbouring k1 per lane
+    constexpr int HALF = S::ROW_TILE / 2;
+    cf4 nxt[PER];
     auto fetch = [&](int f) {
         const cf* const yf = Y + static_cast<size_t>(f) * S::N + S::ROW_TILE * ktile;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int idx = i * kWG + tid;
-            nxt[i] = yf[static_cast<size_t>(idx / S::ROW_TILE) * N1 + idx % S::ROW_TILE];
+            nxt[i] = *reinterpret_cast<const cf4*>(yf + static_cast<size_t>(idx / HALF) * N1 + 2 * (idx % HALF));
         }
     };
     if (fg < nframes) fetch(fg);
@@ -216,7 +227,9 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_rows_kernel(const cf* __restr
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int idx = i * kWG + tid;
-            tile[(idx / S::ROW_TILE) * S::ROW_PITCH + idx % S::ROW_TILE] = nxt[i];
+            cf* const dst = tile + (idx / HALF) * S::ROW_PITCH + 2 * (idx % HALF);
+            dst[0] = nxt[i].lo;
+            dst[1] = nxt[i].hi;
         }
         __syncthreads();
         if (f + ngroups < nframes) fetch(f + ngroups);
@@ -600,10 +613,12 @@ __global__ __launch_bounds__(kWG, 4) void bluestein_mid_kernel(const cf* __restr
         const cf* const yf = Y + static_cast<size_t>(f) * S::N + S::ROW_TILE * ktile;
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < N2 * S::ROW_TILE / kWG; ++i) {
+        for (int i = 0; i < N2 * S::ROW_TILE / kWG / 2; ++i) {          // 16-byte loads
             const int idx = i * kWG + tid;
-            const int n2 = idx / S::ROW_TILE, j = idx % S::ROW_TILE;
-            tile[n2 * S::ROW_PITCH + j] = yf[static_cast<size_t>(n2) * N1 + j];
+            const int n2 = idx / (S::ROW_TILE / 2), j = 2 * (idx % (S::ROW_TILE / 2));
+            const cf4 v = *reinterpret_cast<const cf4*>(yf + static_cast<size_t>(n2) * N1 + j);
+            tile[n2 * S::ROW_PITCH + j] = v.lo;
+            tile[n2 * S::ROW_PITCH + j + 1] = v.hi;
         }
         __syncthreads();
         const int k1 = S::ROW_TILE * ktile + jrow;
@@ -631,7 +646,13 @@ __global__ __launch_bounds__(kWG, 4) void bluestein_mid_kernel(const cf* __restr
         exchange_sync<false>();
         cf* const row = Y2 + (static_cast<size_t>(f) * N1 + k1) * N2;
 #pragma unroll
-        for (int a = 0; a < G::P; ++a) row[t + T * a] = slab[G::slot(t + T * a)];
+        for (int a = 0; a < G::P / 2; ++a) {                              // 16-byte stores
+            const int e = 2 * t + 2 * T * a;
+            cf4 v;
+            v.lo = slab[G::slot(e)];
+            v.hi = slab[G::slot(e + 1)];
+            *reinterpret_cast<cf4*>(row + e) = v;
+        }
         exchange_sync<false>();
     }
 }
