@@ -293,21 +293,35 @@ __device__ __forceinline__ unsigned ctl_load(const unsigned* p)
 // Team barrier in two halves.  arrive: every thread's global stores are in the L2 (vmcnt) and
 // its loads have returned before thread 0 counts the workgroup in.  wait: thread 0 polls the
 // team's counter (bounded), everybody else parks at the workgroup barrier.
+// Current value of a counter by way of a returning atomic add of zero, written in assembly: the
+// compiler turns `fetch_add(p, 0)` at workgroup scope into a plain (sc0) load, which the CU's L1
+// serves -- stale for ever once the line is resident.  An atomic always executes in the L2.
+__device__ __forceinline__ unsigned l2_atomic_read(unsigned* p)
+{
+    unsigned r;
+    const unsigned zero = 0;
+    asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p), "v"(zero) : "memory");
+    return r;
+}
+
+// The team's counter is only ever touched by read-modify-write atomics WITHOUT the sc1 bit
+// (workgroup scope in the language): they execute in the XCD's L2, which all members share --
+// an L2 round trip per poll instead of a trip to the memory-side coherence point.
 __device__ __forceinline__ void team_arrive(FusedCtl* ctl, int xcd)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0)
-        __hip_atomic_fetch_add(&ctl->barrier[xcd][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&ctl->barrier[xcd][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ bool team_wait(FusedCtl* ctl, int xcd, unsigned target, int* ok_flag)
 {
     if (threadIdx.x == 0) {
         unsigned spins = 0;
         int ok = 1;
-        while (ctl_load(&ctl->barrier[xcd][0]) < target) {
+        while (l2_atomic_read(&ctl->barrier[xcd][0]) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > kSpinLimit || ctl_load(&ctl->abort[0]) != 0) {
+            if (++spins > kSpinLimit || ((spins & 1023u) == 0 && ctl_load(&ctl->abort[0]) != 0)) {
                 __hip_atomic_store(&ctl->abort[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
                 break;
@@ -362,9 +376,10 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SLAB_CPX = (S::SLAB_A > S::SLAB_B ? S::SLAB_A : S::SLAB_B);
     cf* const slabs = reinterpret_cast<cf*>(smem);                                     // [16][SLAB_CPX]
-    unsigned char* const area = smem + kWaves * SLAB_CPX * sizeof(cf);                 // raw rows | Y tile
-    uint8_t* const raw = area;                                                         // [N1][PITCH] dwords
+    unsigned char* const area = smem + kWaves * SLAB_CPX * sizeof(cf);
     cf* const tile = reinterpret_cast<cf*>(area);                                      // [N2][ROW_PITCH]
+    uint8_t* const raw = area + N2 * S::ROW_PITCH * sizeof(cf);                        // [N1][PITCH] dwords: its own
+    // region, so that the next round's rows can be staged (LDS-DMA) while phase B works on the tile
     __shared__ int team[4];
 
     const int tid = threadIdx.x;
@@ -397,14 +412,32 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
 
     // Per-lane constants are re-derived at the top of every round from an opaque copy of the thread
     // index: hoisted out of the loop they (and every address built from them) would stay live across
-    // both phases and spill at 128 VGPRs.  The sub-transform twiddles are re-read from their
-    // L2-resident tables per phase for the same reason, and the f64 accumulators are parked in LDS
-    // outside phase B: behind the raw rows (free while phase A runs, part of the Y tile in phase B).
-    {
-        double* const park0 = reinterpret_cast<double*>(area + ((N1 * PITCH * 4 + 15) / 16) * 16) + tid;
+    // both phases and spill at 128 VGPRs.  For the same reason the sub-transform twiddles are
+    // (re)loaded per phase -- ahead of the barrier wait that precedes their use.
+    double acc[P];
 #pragma unroll
-        for (int a = 0; a < P; ++a) park0[a * kWG] = 0.0;
-    }
+    for (int a = 0; a < P; ++a) acc[a] = 0.0;
+
+    // raw rows of (frame f, tile tl) -> LDS, asynchronously (LDS-DMA) when DMA
+    auto stage_rows = [&](int f, int tid_) {
+        const uint8_t* const frame = stream + static_cast<size_t>(f) * (2 * N);
+#pragma unroll 1
+        for (int i = 0; i < (N1 * PITCH + kWG - 1) / kWG; ++i) {
+            const int L = i * kWG + tid_;
+            const int rr = L / PITCH, d = L % PITCH;
+            if (L < N1 * PITCH && d < COLS / 2) {
+                const uint8_t* src = frame + 2 * (static_cast<size_t>(N2) * rr + COLS * tl) + 4 * d;
+                if constexpr (DMA) {
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(raw + 4 * (i * kWG + wave * 64)), 4, 0, 0);
+                } else {
+                    const uint16_t lo = *reinterpret_cast<const uint16_t*>(src);
+                    const uint16_t hi = *reinterpret_cast<const uint16_t*>(src + 2);
+                    *reinterpret_cast<uint32_t*>(raw + 4 * L) = lo | (static_cast<uint32_t>(hi) << 16);
+                }
+            }
+        }
+    };
+    if (xcd * FR + fsl < nframes && xcd < (nframes + FR - 1) / FR) stage_rows(xcd * FR + fsl, tid);
 
     const int nrounds = (nframes + FR - 1) / FR;
     FusedClock fclk;
@@ -425,27 +458,10 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
         const float sgn = (c & 1) ? -1.0f : 1.0f;               // (-1)^n, n = N2 n1 + n2
         const float off = -(kTwo23 + 127.0f) * sgn;
         const int jrow = wave * S::SUBB + subB;                 // this lane group's row inside the tile
-        double* const park = reinterpret_cast<double*>(area + ((N1 * PITCH * 4 + 15) / 16) * 16) + tid_;
+
         // ---- phase A: columns of tile tl -> LDS slabs (natural k1 order) ------------------------
-        if (valid) {
-            const uint8_t* const frame = stream + static_cast<size_t>(f) * (2 * N);
-#pragma unroll 1
-            for (int i = 0; i < (N1 * PITCH + kWG - 1) / kWG; ++i) {
-                const int L = i * kWG + tid_;
-                const int rr = L / PITCH, d = L % PITCH;
-                if (L < N1 * PITCH && d < COLS / 2) {
-                    const uint8_t* src = frame + 2 * (static_cast<size_t>(N2) * rr + COLS * tl) + 4 * d;
-                    if constexpr (DMA) {
-                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(raw + 4 * (i * kWG + wave * 64)), 4, 0, 0);
-                    } else {
-                        const uint16_t lo = *reinterpret_cast<const uint16_t*>(src);
-                        const uint16_t hi = *reinterpret_cast<const uint16_t*>(src + 2);
-                        *reinterpret_cast<uint32_t*>(raw + 4 * L) = lo | (static_cast<uint32_t>(hi) << 16);
-                    }
-                }
-            }
-            if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // (this round's raw rows were staged ahead: before the loop, or during the previous phase B)
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         FSTAMP(0);                       // raw rows staged
         if (valid) {
@@ -465,12 +481,17 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                     x[a] = v * sgn + off;
                 }
             }
+            // the inter-step twiddles of this column: issued now, used after the transform
+            cf wstep[P];
+#pragma unroll
+            for (int a = 0; a < P; ++a)          // read once per round: streamed past the L2 (nt), Y keeps its lines
+                wstep[a] = __builtin_nontemporal_load(twN + static_cast<size_t>(c) * N1 + TA * a + tA);
             group_fft<GA>(tA, x, twA, slabA);
             exchange_sync<false>();
 #pragma unroll
             for (int a = 0; a < P; ++a) {
                 const int k1 = bin_of<GA>(tA, a);
-                slabA[GA::slot(k1)] = cmul(x[a], twN[static_cast<size_t>(c) * N1 + TA * a + tA]);
+                slabA[GA::slot(k1)] = cmul(x[a], wstep[a]);
             }
             exchange_sync<false>();
         }
@@ -482,37 +503,53 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
         if (valid) {
             cf* const yrow = Y + static_cast<size_t>(c) * N1;
 #pragma unroll
-            for (int a = 0; a < P; ++a) yrow[tA + TA * a] = slabA[GA::slot(tA + TA * a)];
+            for (int a = 0; a < P / 2; ++a) {
+                const int e = 2 * tA + 2 * TA * a;
+                cf4 v;
+                v.lo = slabA[GA::slot(e)];
+                v.hi = slabA[GA::slot(e + 1)];
+                *reinterpret_cast<cf4*>(yrow + e) = v;
+            }
         }
         // ---- barrier 1: the round's Y is complete in the team's L2 --------------------------------
         team_arrive(ctl, xcd);
         FSTAMP(3);                       // Y rows written (stores drained)
+        cf twB[GB::NPASS - 1][P - 1];   // issued ahead of the wait they hide behind
+        load_twiddles<GB, 1>(tB, tw_n2, twB);
         if (!team_wait(ctl, xcd, ++bar * 32u, &team[3])) return;
         FSTAMP(4);                       // barrier 1
         // ---- phase B: rows of tile tl ---------------------------------------------------------------
-        double acc[P];
-#pragma unroll
-        for (int a = 0; a < P; ++a) acc[a] = park[a * kWG];
-        __syncthreads();                // ... before the tile overwrites the parking area
         if (valid) {
             const cf* const yt = Y + S::ROW_TILE * tl;
+            // sc1 loads: served by the L2, never by this CU's L1 (other CUs wrote these lines);
+            // 16 bytes per lane, all of a thread's loads in flight before the first use
+            constexpr int PERB = N2 * S::ROW_TILE / kWG / 2;
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            f4 v[PERB];
 #pragma unroll
-            for (int i = 0; i < N2 * S::ROW_TILE / kWG; ++i) {
+            for (int i = 0; i < PERB; ++i) {
                 const int idx = i * kWG + tid_;
-                const int n2 = idx / S::ROW_TILE, j = idx % S::ROW_TILE;
-                // sc1: served by the L2, bypassing this CU's L1 (other CUs wrote these lines)
-                const unsigned long long bits = __hip_atomic_load(
-                    reinterpret_cast<const unsigned long long*>(yt + static_cast<size_t>(n2) * N1 + j),
-                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                tile[n2 * S::ROW_PITCH + j] = __builtin_bit_cast(cf, bits);
+                const int n2 = idx / (S::ROW_TILE / 2), j = 2 * (idx % (S::ROW_TILE / 2));
+                const cf* src = yt + static_cast<size_t>(n2) * N1 + j;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[i]) : "v"(src) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < PERB; ++i) {
+                const int idx = i * kWG + tid_;
+                const int n2 = idx / (S::ROW_TILE / 2), j = 2 * (idx % (S::ROW_TILE / 2));
+                // (the "+v" ties each value to the wait above: the loads are opaque to the compiler)
+                asm volatile("" : "+v"(v[i]));
+                tile[n2 * S::ROW_PITCH + j] = cf{v[i].x, v[i].y};
+                tile[n2 * S::ROW_PITCH + j + 1] = cf{v[i].z, v[i].w};
             }
         }
         team_arrive(ctl, xcd);          // this member is done with Y (its tile is in LDS)
         ++bar;
         FSTAMP(5);                       // Y tile loaded
+        // next round's raw rows: in flight while the rows are transformed
+        if (r + 8 < nrounds && (r + 8) * FR + fsl < nframes) stage_rows((r + 8) * FR + fsl, tid_);
         if (valid) {
-            cf twB[GB::NPASS - 1][P - 1];
-            load_twiddles<GB, 1>(tB, tw_n2, twB);
             cf x[P];
 #pragma unroll
             for (int a = 0; a < P; ++a) x[a] = tile[(tB + TB * a) * S::ROW_PITCH + jrow];
@@ -521,8 +558,6 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
             exchange_sync<false>();
         }
         __syncthreads();        // tile/slabs are reused by the next round's phase A
-#pragma unroll
-        for (int a = 0; a < P; ++a) park[a * kWG] = acc[a];
         FSTAMP(6);                       // row transforms + accumulate
     }
     fclk.publish();
@@ -532,11 +567,6 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
     const int lane = tid & 63;
     const int subB = lane / TB, tB = lane % TB;
     const int jrow = wave * S::SUBB + subB;
-    double* const park = reinterpret_cast<double*>(area + ((N1 * PITCH * 4 + 15) / 16) * 16) + tid;
-    double acc[P];
-#pragma unroll
-    for (int a = 0; a < P; ++a) acc[a] = park[a * kWG];
-    __syncthreads();
     double* const stage = reinterpret_cast<double*>(smem);                          // [N2 k2][ROW_PITCH]
 #pragma unroll
     for (int a = 0; a < P; ++a) stage[bin_of<GB>(tB, a) * S::ROW_PITCH + jrow] = acc[a];
@@ -704,9 +734,9 @@ template <class S>
 constexpr int fused_lds_bytes()
 {
     constexpr int slab = (S::SLAB_A > S::SLAB_B ? S::SLAB_A : S::SLAB_B) * kWaves * (int)sizeof(cf);
-    constexpr int raw = (S::N1 * (16 * S::SUBA / 2 + 1) * 4 + 15) / 16 * 16 + kWG * 8 * (int)sizeof(double);   // + parked accumulators
+    constexpr int raw = S::N1 * (16 * S::SUBA / 2 + 1) * 4;
     constexpr int tile = S::N2 * S::ROW_PITCH * (int)sizeof(cf);
-    return slab + (raw > tile ? raw : tile);
+    return slab + tile + raw;
 }
 
 template <int N1, int N2>

@@ -200,3 +200,40 @@ def test_c4_full_size_on_its_own_stream(c4):
     assert e_gpu["total"] < 3e-7
     # the lines: the bar, or -- where float32 itself gives out -- not behind the other float32 FFTs
     assert e_gpu["lines"] < max(PARITY, 1.25 * max(e_orc["lines"], e_roc["lines"]))
+
+
+def _bench_line(args, env_extra=None, nproc=0):
+    import subprocess
+    import sys
+    env = dict(os.environ, **(env_extra or {}))
+    if nproc:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+               "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.split("\n") if l.strip()]
+    assert len(lines) == 1, "bench.py must print exactly one line on stdout: %r" % lines[:3]
+    return json.loads(lines[0])
+
+
+def test_bench_c5_line_through_rccl_is_checked_against_the_fixtures():
+    """bench.py --workload C5 with torch.distributed initialised (RCCL, world size 1 on this box):
+    the strong-scaling line carries the check of the REDUCED spectra against the committed C5
+    fixtures, and stdout is the one JSON line (RCCL's banner goes to stderr)."""
+    d = _bench_line(["--workload", "C5", "--force-dist", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["config"]["reduce"].startswith("one async RCCL reduce")
+    assert d["check"]["hops"] == 8 and d["check"]["reduced_spectra_vs_float64_fixtures_max_rel"] < 1e-6
+    assert d["value"] > 5e10 and d["roofline"]["frac"] > 0.05
+
+
+def test_bench_c5_two_ranks():
+    """Two processes, two GPUs: hop-major shards, one RCCL reduce per scan, reduced spectra checked."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box: the 2-rank RCCL run needs two")
+    d = _bench_line(["--gpus", "2", "--steps", "8", "--warmup", "2"], nproc=2)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["check"]["reduced_spectra_vs_float64_fixtures_max_rel"] < 1e-6
+    assert d["one_gpu_same_workload"]["value"] > 0
