@@ -223,6 +223,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the reduce even with one rank")
     ap.add_argument("--workload", choices=["auto", "C2", "C3", "C4", "C5"], default="auto")
+    ap.add_argument("--shard-as", type=int, default=0,
+                    help="(diagnostic) C5: process only the shard rank 0 of a job of this many ranks would own -- "
+                         "shows whether the per-step host work keeps up with an 8-GPU step on one GPU; the line's value is then meaningless")
     ap.add_argument("--event-every", type=int, default=8,
                     help="bracket the fused kernel with HIP events on every k-th timed step")
     args = ap.parse_args()
@@ -262,7 +265,7 @@ def main():
     # ---- workload ------------------------------------------------------------------------
     # what this rank processes per step: list of (hop, first_frame, frames)
     if strong:
-        mine = rpf.sharding.shard_hops(hops, R, world, rank)
+        mine = rpf.sharding.shard_hops(hops, R, args.shard_as or world, rank)
     else:
         mine = [(0, 0, R)]
     # the streams, generated on the device (bit-identical to synth.noise_tones_iq)
@@ -377,7 +380,7 @@ def main():
 
     # ---- C5: the reduced spectra of the last scan against the committed fixtures -----------------
     check = None
-    if strong and rank == 0:
+    if strong and rank == 0 and not args.shard_as:
         got = d_pwr[last_blk].cpu().numpy()
         worst = 0.0
         for hop in range(hops):

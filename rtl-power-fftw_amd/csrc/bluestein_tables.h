@@ -36,13 +36,18 @@ inline void fft_pow2(std::vector<std::complex<long double>>& a)
         j ^= bit;
         if (i < j) std::swap(a[i], a[j]);
     }
+    // W_n^j, j < n/2, evaluated once (the generic path plans lengths up to 2^21)
     const long double pi = 3.141592653589793238462643383279502884L;
+    std::vector<std::complex<long double>> w(n / 2 ? n / 2 : 1);
+    for (size_t j = 0; j < n / 2; ++j) {
+        const long double ang = -2 * pi * static_cast<long double>(j) / static_cast<long double>(n);
+        w[j] = std::complex<long double>(std::cos(ang), std::sin(ang));
+    }
     for (size_t len = 2; len <= n; len <<= 1) {
+        const size_t step = n / len;
         for (size_t i = 0; i < n; i += len)
             for (size_t k = 0; k < len / 2; ++k) {
-                const long double ang = -2 * pi * static_cast<long double>(k) / static_cast<long double>(len);
-                const std::complex<long double> w(std::cos(ang), std::sin(ang));
-                const std::complex<long double> u = a[i + k], v = a[i + k + len / 2] * w;
+                const std::complex<long double> u = a[i + k], v = a[i + k + len / 2] * w[k * step];
                 a[i + k] = u + v;
                 a[i + k + len / 2] = u - v;
             }

@@ -89,6 +89,8 @@ struct rpf_engine {
     void* d_fused_ctl = nullptr;          // its team counters / abort flag
     bool bluestein = false;               // N handled by the Bluestein kernel (chirp tables below)
     bool bigblu = false;                  // N handled by the large (four-step) Bluestein path
+    bool generic = false;                 // N handled by the catch-all Stockham path (rpf_generic.hip)
+    int gen_h = 0;                        // its two-level twiddle split (d_tw_sub = T0, d_tw_sub2 = T1)
     int blu_M = 0;                        // bigblu: convolution length (partial spectra have M entries)
     rpf::cf* d_chirp = nullptr;           // g[n], N entries
     rpf::cf* d_bhat = nullptr;            // frequency-domain chirp, M entries
@@ -171,6 +173,13 @@ int launch_transform(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, hi
                                         e->d_partial, e->plan.grid, stream));
         e->last = e->plan;
         *nslots = rpf::fourstep_partial_slots(e->N);
+        return RPF_OK;
+    }
+    if (e->generic) {
+        HIP_TRY(e, rpf::launch_generic(e->N, d_frames, nframes, e->d_window, e->d_chirp, e->d_bhat, e->d_tw_sub,
+                                       e->d_tw_sub2, e->gen_h, e->d_scratch, e->d_partial, /*accumulate=*/false, stream));
+        e->last = e->plan;
+        *nslots = 1;
         return RPF_OK;
     }
     if (e->bigblu) {
@@ -384,7 +393,7 @@ int rpf_abi_version(void) { return RPF_ABI_VERSION; }
 int rpf_supported_n(int N)
 {
     return (rpf::kernel_supported(N) || rpf::fourstep_supported(N) || rpf::bluestein_supported(N) ||
-            rpf::bigblu_supported(N)) ? 1 : 0;
+            rpf::bigblu_supported(N) || rpf::generic_supported(N)) ? 1 : 0;
 }
 
 const char* rpf_last_global_error(void) { return g_last_error.c_str(); }
@@ -402,10 +411,12 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
     const bool fourstep = rpf::fourstep_supported(cfg->N) && variant == 0;
     const bool bluestein = rpf::bluestein_supported(cfg->N) && variant == 0;
     const bool bigblu = rpf::bigblu_supported(cfg->N) && variant == 0;
-    if (!fourstep && !bluestein && !bigblu && !rpf::kernel_supported(cfg->N, variant))
+    const bool tuned = fourstep || bluestein || bigblu || rpf::kernel_supported(cfg->N, variant);
+    const bool generic = !tuned && variant == 0 && rpf::generic_supported(cfg->N);
+    if (!tuned && !generic)
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT,
                     "No gfx950 kernel for " + std::to_string(cfg->N) +
-                        " bins in this build (supported: every even N up to 131072 and the powers of two up to 262144).");
+                        " bins in this build (supported: every even N up to 1048576 and the powers of two up to 16777216).");
     if (cfg->n_buffers < 1)
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT, "Argument to 'buffers' must be a positive number.");
     if (cfg->buffer_capacity < 2 || (cfg->buffer_capacity % 2) != 0)
@@ -433,6 +444,7 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
     e->fourstep = fourstep;
     e->bluestein = bluestein;
     e->bigblu = bigblu;
+    e->generic = generic;
     e->queue_histogram.assign(e->n_buffers + 1, 0);
     e->pwr.assign(e->N, 0.0);
 
@@ -458,16 +470,19 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
     std::vector<rpf::cf> tw;
     int blu_m1 = 0, blu_m2 = 0;
     if (e->bigblu) rpf::bigblu_lengths(e->N, &e->blu_M, &blu_m1, &blu_m2);
-    rpf::make_twiddles(e->bluestein ? rpf::bluestein_length(e->N) : e->bigblu ? e->blu_M : e->N, tw);
-    CREATE_TRY(hipMalloc(&e->d_twiddles, sizeof(rpf::cf) * tw.size()));
-    CREATE_TRY(hipMemcpy(e->d_twiddles, tw.data(), sizeof(rpf::cf) * tw.size(), hipMemcpyHostToDevice));
+    if (!e->generic) {
+        rpf::make_twiddles(e->bluestein ? rpf::bluestein_length(e->N) : e->bigblu ? e->blu_M : e->N, tw);
+        CREATE_TRY(hipMalloc(&e->d_twiddles, sizeof(rpf::cf) * tw.size()));
+        CREATE_TRY(hipMemcpy(e->d_twiddles, tw.data(), sizeof(rpf::cf) * tw.size(), hipMemcpyHostToDevice));
+    }
     if (e->has_window) {
         CREATE_TRY(hipMalloc(&e->d_window, sizeof(float) * e->N));
         CREATE_TRY(hipMemcpy(e->d_window, cfg->window, sizeof(float) * e->N, hipMemcpyHostToDevice));
     }
     size_t partial_slots = 0, partial_len = e->N;
     std::vector<float> blu_g, blu_bhat;
-    if (e->bluestein || e->bigblu) {
+    const bool gen_blu = e->generic && rpf::generic_length(e->N) != e->N;
+    if (e->bluestein || e->bigblu || gen_blu) {
         std::vector<float>&g = blu_g, &bhat = blu_bhat;
         rpf::make_bluestein_tables(e->N, cfg->window, g, bhat);
         CREATE_TRY(hipMalloc(&e->d_chirp, sizeof(float) * g.size()));
@@ -475,7 +490,22 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         CREATE_TRY(hipMalloc(&e->d_bhat, sizeof(float) * bhat.size()));
         CREATE_TRY(hipMemcpy(e->d_bhat, bhat.data(), sizeof(float) * bhat.size(), hipMemcpyHostToDevice));
     }
-    if (e->bluestein) {
+    if (e->generic) {
+        std::vector<rpf::cf> t0, t1;
+        rpf::generic_twiddle_tables(e->N, t0, t1, &e->gen_h);
+        CREATE_TRY(hipMalloc(&e->d_tw_sub, sizeof(rpf::cf) * t0.size()));
+        CREATE_TRY(hipMemcpy(e->d_tw_sub, t0.data(), sizeof(rpf::cf) * t0.size(), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc(&e->d_tw_sub2, sizeof(rpf::cf) * t1.size()));
+        CREATE_TRY(hipMemcpy(e->d_tw_sub2, t1.data(), sizeof(rpf::cf) * t1.size(), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc(&e->d_scratch, rpf::generic_scratch_bytes(e->N)));
+        hipDeviceProp_t prop;
+        CREATE_TRY(hipGetDeviceProperties(&prop, e->device));
+        e->plan.grid = prop.multiProcessorCount;
+        e->plan.block = 256;
+        e->plan.fpw = rpf::generic_batch(e->N);
+        e->plan.lds_bytes = 0;
+        partial_slots = 1;
+    } else if (e->bluestein) {
         CREATE_TRY(rpf::plan_bluestein(e->N, e->device, &e->plan));
         partial_slots = e->plan.grid;
     } else if (e->bigblu) {

@@ -91,6 +91,18 @@ hipError_t launch_bigblu(int N, bool use_dma, const uint8_t* d_stream, long nfra
                          const cf* d_tw_m2, const cf* d_step_tw, const cf* d_step_tw2, const cf* d_g_t,
                          const cf* d_bhat_t, cf* d_scratch, double* d_partial, int max_grid, hipStream_t stream);
 
+// ---- generic path (rpf_generic.hip): every other even N -- powers of two up to 2^24, others up to 2^20 --
+bool generic_supported(int N);
+int generic_length(int N);              // N, or Bluestein's M = 2^ceil(log2(2N-1))
+int generic_batch(int N);
+size_t generic_scratch_bytes(int N);
+void generic_twiddle_tables(int N, std::vector<cf>& t0, std::vector<cf>& t1, int* h);
+// d_pwr[N] = (accumulate ? d_pwr : 0) + sum over the frames; d_window: N floats or null (powers of two);
+// d_g (N) / d_bhat (M): bluestein_tables.h's tables (other N).
+hipError_t launch_generic(int N, const uint8_t* d_stream, long nframes, const float* d_window, const cf* d_g,
+                          const cf* d_bhat, const cf* d_t0, const cf* d_t1, int h, cf* d_scratch, double* d_pwr,
+                          bool accumulate, hipStream_t stream);
+
 // Master twiddle table W_N^k = exp(-2 pi i k / N), k in [0,N), evaluated in
 // long double and rounded once to float.
 void make_twiddles(int N, std::vector<cf>& out);

@@ -208,6 +208,30 @@ def test_large_non_power_of_two_sizes_match_oracle(N, torch_dev):
         assert max_err_over_mean(got, o32) < PARITY
 
 
+@pytest.mark.parametrize("N,windows", [(131074, (False, True)), (524288, (False,)), (999998, (True,)), (1048576, (False,))])
+def test_catch_all_sizes_match_oracle(N, windows, torch_dev):
+    """Every even N the tuned kernels do not cover (rpf_generic.hip: Stockham passes through
+    HBM, Bluestein on top for lengths that are not powers of two) -- the reference takes any
+    even N (params.cxx:150-155).  Device and queue paths (frames straddle the 1.6 MB buffers),
+    windowed and not, against the float32 oracle and float64 truth."""
+    R = 3
+    stream = rpf.synth.uniform_iq(600 + N % 53, N * R + N // 2)
+    for windowed in windows:
+        w = rpf.synth.hann_window(N) + np.float32(0.25) if windowed else None
+        with rpf.Datastore(rpf.Params(N=N, window=windowed, repeats=R), w) as ds:
+            got, n = run_device(ds, stream, R, torch_dev)
+            again, _ = run_device(ds, stream, R, torch_dev)
+            host, done = ds.accumulate(stream, R)
+        assert n == done == R
+        assert np.array_equal(got, again)
+        assert max_rel(host, got) < 1e-13
+        truth = truth_f64(N, stream, R, w)
+        assert max_err_over_mean(got, truth) < PARITY
+        o32, _ = oracle_accumulate(N, stream, R, w, 32)
+        assert max_err_over_mean(got, o32) < PARITY
+        assert abs(got.sum() / truth.sum() - 1) < 5e-7
+
+
 def test_known_answers_on_device(torch_dev):
     N, R = 4096, 1000
     with rpf.Datastore(rpf.Params(N=N, repeats=R)) as ds:
