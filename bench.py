@@ -205,6 +205,17 @@ def secondary_limits(N, frames_per_launch, kernel_s):
         out["lds_frac"] = mix["lds_cycles_per_wave_iteration"] * mix["waves"] * iters / lds_cycles_avail
         out["source"] = "profiles/isa_mix.json (%s) x MI355X_MICROARCH.md cycle tables at %.1f GHz" % (
             mix.get("kernel", "?"), CLOCK_GHZ)
+        # the same VALU work priced at the packed-f32 issue rate this chip SUSTAINS with every SIMD busy
+        # (tools/lds_valu_bench, profiles/valu_rate.json): the clock sags well below 2.4 GHz under that load
+        try:
+            rate = json.load(open(os.path.join(ROOT, "profiles", "valu_rate.json")))
+            pk_ns = rate["pk_fma_ns_per_instruction_per_simd"]
+            valu_s = mix["valu_cycles_per_wave_iteration"] / 4.0 * pk_ns * 1e-9 * mix["waves"] * iters / (N_CUS * 4)
+            out["valu_frac_of_sustained_pk_rate"] = valu_s / kernel_s
+            out["sustained_pk_rate_source"] = "profiles/valu_rate.json: %.3f ns per v_pk_fma_f32 per SIMD (captured %s)" % (
+                pk_ns, rate.get("captured"))
+        except Exception:
+            pass
     return out
 
 
@@ -378,6 +389,22 @@ def main():
             break
     elapsed = float(np.median(regions))
 
+    # ---- the dominant kernel alone, four launches per event pair (amortises the event packets'
+    # own cost; informational, the roofline uses the in-region brackets above) ------------------------
+    b2b_ms = None
+    if rank == 0:
+        hop0, first0, count0 = mine[0]
+        pairs = []
+        for j in range(48):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for q in range(4):
+                ds.device_fused(bufs[(4 * j + q) % nb][0].data_ptr(), 2 * N * count0, count0, s)
+            e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        b2b_ms = float(np.median([a.elapsed_time(b) for a, b in pairs[8:]])) / 4.0
+
     # ---- C5: the reduced spectra of the last scan against the committed fixtures -----------------
     check = None
     if strong and rank == 0 and not args.shard_as:
@@ -442,6 +469,7 @@ def main():
                     "traffic_source": ("NOT measured in this run: rocprofv3 PMC capture replayed from profiles/traffic.json -- "
                                        + str(traffic_note)) if traffic else None,
                     "kernel": kernel, "kernel_ms": k1_ms, "kernel_ms_samples": len(events),
+                    "kernel_ms_back_to_back": b2b_ms,       # 4 launches per event pair, after the timed regions
                     "algorithmic_bytes_per_launch": alg_bytes, "frames_per_launch": frames_per_launch,
                     "samples_per_s_kernel_only": N * frames_per_launch / (k1_ms * 1e-3),
                     # the contracted roofline is HBM read; what actually limits the kernel:

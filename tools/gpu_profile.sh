@@ -35,4 +35,8 @@ cd $ROOT
 [ -x tools/lds_valu_bench ] && timeout 120 tools/lds_valu_bench > $OUT/lds_valu.txt 2>&1
 timeout 200 python tools/gpu_fixed_cost.py > $OUT/k1_fixed_cost.txt 2>&1
 timeout 600 python tools/gpu_sweep.py 64:0 128:0 256:0 512:0 1024:0 2048:0 4096:0 8192:0 16384:0 32768:0 65536:0 131072:0 262144:0 500:0 1000:0 3000:0 4094:0 5000:0 20000:0 100000:0 131070:0 524288:0 > $OUT/sizes.txt 2>&1
-ls $OUT | head -60
+# condense here: the raw rocprofv3 output is far beyond what gpurun copies back
+python tools/summarize_profile.py $TAG > $OUT/summarize.log 2>&1
+tail -3 $OUT/summarize.log
+for d in $OUT/*_trace $OUT/*_pmc_* ; do [ -d "$d" ] && rm -rf "$d"; done
+du -sh $OUT; ls $OUT/summary

@@ -1,101 +1,157 @@
 #!/usr/bin/env python3
-"""Condenses gpurun_out/<tag>/ (written by tools/gpu_profile.sh on the GPU box)
-into the tracked files under profiles/:
-  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (verbatim)
-  profiles/<tag>_counters.json      per-launch means of the PMC passes for K1 / K3
-  profiles/<tag>_bench.json         the bench.py line of the same run
-  profiles/traffic.json             HBM bytes per K1 launch, read by bench.py
-HBM bytes follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are
-collected in separate --pmc passes, are in KiB, and on gfx950 FETCH_SIZE reports
-half the bytes of a wide coalesced read -- calibrated in the same run on
-torch's roll kernel, which reads exactly 81 920 000 B per launch."""
+"""Condenses gpurun_out/<tag>/ (written by tools/gpu_profile.sh on the GPU box) into small
+summaries under gpurun_out/<tag>/summary/ -- run ON the box, because the raw rocprofv3 output
+is far beyond what gpurun copies back -- which are then copied into the tracked profiles/:
+
+  <tag>_bench.json, <tag>_bench_20steps.json, <tag>_c3_bench.json, <tag>_c4_bench.json,
+  <tag>_c5_bench.json            the bench.py lines of the same session
+  <tag>_kernel_stats.csv, <tag>_c3_kernel_stats.csv, <tag>_c4_kernel_stats.csv
+                                 rocprofv3 --kernel-trace --stats summaries (verbatim)
+  <tag>_counters.json            per-launch means of the PMC passes (K1, K3, four-step kernels)
+  traffic.json                   HBM bytes per launch / acquisition, read by bench.py
+  valu_rate.json                 sustained packed-f32 issue rate (tools/lds_valu_bench), read by bench.py
+  <tag>_hbm_read.txt, <tag>_lds_valu.txt, <tag>_k1_fixed_cost.txt, <tag>_sizes.txt
+
+HBM bytes follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are collected in
+separate --pmc passes, are in KiB, and on gfx950 FETCH_SIZE reports half the bytes of a wide
+coalesced read -- checked in the same run on torch's roll kernel, which reads exactly
+81 920 000 B per launch."""
 import collections
 import csv
+import glob
 import json
 import os
+import re
 import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", tag)
-dst = os.path.join(ROOT, "profiles")
+dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
 
-shutil.copy(os.path.join(src, "trace", "c2_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
-shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, tag + "_bench.json"))
+
+def find(sub, name):
+    hits = glob.glob(os.path.join(src, sub, "**", name), recursive=True)
+    return hits[0] if hits else None
 
 
-def means(path, full_grid_only=True):
+def copy(path, name):
+    if path and os.path.exists(path):
+        shutil.copy(path, os.path.join(dst, name))
+
+
+for name in ("bench.json", "bench_20steps.json", "c3_bench.json", "c4_bench.json", "c5_bench.json"):
+    copy(os.path.join(src, name), tag + "_" + name)
+copy(find("c2_trace", "c2_kernel_stats.csv"), tag + "_kernel_stats.csv")
+copy(find("c3_trace", "c3_kernel_stats.csv"), tag + "_c3_kernel_stats.csv")
+copy(find("c4_trace", "c4_kernel_stats.csv"), tag + "_c4_kernel_stats.csv")
+for name in ("hbm_read.txt", "lds_valu.txt", "k1_fixed_cost.txt", "sizes.txt"):
+    copy(os.path.join(src, name), tag + "_" + name)
+captured = open(os.path.join(src, "captured.txt")).read().strip() if os.path.exists(os.path.join(src, "captured.txt")) else None
+
+
+def classify(name):
+    if "fft_accum_kernel" in name:
+        return "K1_fft_accum"
+    if "reduce_kernel" in name:
+        return "K3_reduce"
+    if "fourstep_cols_kernel" in name:
+        return "K2a_cols"
+    if "fourstep_rows_kernel" in name:
+        return "K2b_rows"
+    if "roll_cuda_kernel" in name or "roll" in name and "kernel" in name:
+        return "calib_roll"
+    return None
+
+
+def rows_of(sub, prefix):
+    path = find(sub, prefix + "_counter_collection.csv")
+    return list(csv.DictReader(open(path))) if path else []
+
+
+def means(rows, full_grid_only=True):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    rows = list(csv.DictReader(open(path)))
-    # the C2 steps launch the full persistent grid; the small correctness check does not
-    full = max([int(r["Grid_Size"]) for r in rows if "fft_accum_kernel" in r["Kernel_Name"]] or [0])
+    k1_grids = [int(r["Grid_Size"]) for r in rows if "fft_accum_kernel" in r["Kernel_Name"]]
+    full = max(k1_grids) if k1_grids else 0
     for r in rows:
-        name = r["Kernel_Name"]
-        if "fft_accum_kernel" in name:
-            k = "K1_fft_accum"
-            if full_grid_only and int(r["Grid_Size"]) < full:
-                continue
-        elif "reduce_kernel" in name:
-            k = "K3_reduce"
-        elif "roll_cuda_kernel" in name:
-            k = "calib_roll_81920000B"
-        else:
+        k = classify(r["Kernel_Name"])
+        if not k:
             continue
+        if k == "K1_fft_accum" and full_grid_only and int(r["Grid_Size"]) < full:
+            continue            # the small correctness check before the timed steps
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}, \
+           {k: {c: (sum(v), len(v)) for c, v in d.items()} for k, d in acc.items()}
 
 
-out = {}
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
-    p = os.path.join(src, sub, "c2_counter_collection.csv")
-    if os.path.exists(p):
-        for k, d in means(p).items():
-            out.setdefault(k, {}).update(d)
+out = {"captured": captured}
+traffic = {"captured": captured,
+           "source": "profiles/%s_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x2 per "
+                     "MI355X_MICROARCH.md, checked on a kernel that reads exactly 81 920 000 B)" % tag}
+for cfg in ("c2", "c3"):
+    merged = {}
+    for sub in ("%s_pmc_FETCH_SIZE" % cfg, "%s_pmc_WRITE_SIZE" % cfg) + (("c2_pmc_sq", "c2_pmc_lds") if cfg == "c2" else ()):
+        m, _ = means(rows_of(sub, cfg))
+        for k, d in m.items():
+            merged.setdefault(k, {}).update(d)
+    out["C2" if cfg == "c2" else "C3_windowed"] = merged
+    k1 = merged.get("K1_fft_accum", {})
+    calib = merged.get("calib_roll", {})
+    if "FETCH_SIZE" in calib and cfg == "c2":
+        out["fetch_size_calibration"] = {
+            "known_bytes": 81920000, "FETCH_SIZE_KiB": calib["FETCH_SIZE"],
+            "bytes_per_reported_byte": 81920000.0 / (calib["FETCH_SIZE"] * 1024.0),
+            "note": "MI355X_MICROARCH.md: FETCH_SIZE reads 1/2 of a wide coalesced stream on gfx950; factor applied = 2"}
+    if "FETCH_SIZE" in k1:
+        traffic["fft_accum_%s_fetch_bytes_per_launch" % cfg] = k1["FETCH_SIZE"] * 1024.0 * 2.0
+    if "WRITE_SIZE" in k1:
+        traffic["fft_accum_%s_write_bytes_per_launch" % cfg] = k1["WRITE_SIZE"] * 1024.0
+    if "FETCH_SIZE" in k1 and "WRITE_SIZE" in k1:
+        traffic["fft_accum_%s_hbm_bytes_per_launch" % cfg] = (traffic["fft_accum_%s_fetch_bytes_per_launch" % cfg] +
+                                                              traffic["fft_accum_%s_write_bytes_per_launch" % cfg])
 
-calib = out.get("calib_roll_81920000B", {})
-fetch_factor = None
-if "FETCH_SIZE" in calib:
-    fetch_factor = 81920000.0 / (calib["FETCH_SIZE"] * 1024.0)
-    out["fetch_size_calibration"] = {
-        "known_bytes": 81920000, "FETCH_SIZE_KiB": calib["FETCH_SIZE"], "bytes_per_reported_byte": fetch_factor,
-        "note": "MI355X_MICROARCH.md: FETCH_SIZE reads 1/2 of a wide coalesced stream on gfx950; factor applied = 2"}
-k1 = out.get("K1_fft_accum", {})
-traffic = {}
-if "FETCH_SIZE" in k1:
-    traffic["fft_accum_c2_fetch_bytes_per_launch"] = k1["FETCH_SIZE"] * 1024.0 * 2.0
-if "WRITE_SIZE" in k1:
-    traffic["fft_accum_c2_write_bytes_per_launch"] = k1["WRITE_SIZE"] * 1024.0
-if traffic:
-    traffic["fft_accum_c2_hbm_bytes_per_launch"] = sum(traffic.values())
-    hb = os.path.join(src, "hbm_read.txt")
-    if os.path.exists(hb):            # tools/hbm_read_bench.hip: read-only stream > Infinity Cache
-        import re
-        m = re.search(r"read-only stream of (\d+) B: .* = (\d+) GB/s", open(hb).read())
-        if m:
-            traffic["measured_read_only_GBps"] = float(m.group(2))
-            traffic["measured_read_only_bytes"] = int(m.group(1))
-            shutil.copy(hb, os.path.join(dst, tag + "_hbm_read.txt"))
-    traffic["source"] = "profiles/%s_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x2 per MI355X_MICROARCH.md)" % tag
-    json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
-# config C3 (windowed kernel), if gpu_profile.sh captured it
-c3 = {}
-for sub in ("c3_pmc_fetch", "c3_pmc_write"):
-    pth = os.path.join(src, sub, "c3_counter_collection.csv")
-    if os.path.exists(pth):
-        c3.update(means(pth).get("K1_fft_accum", {}))
-if "FETCH_SIZE" in c3 and "WRITE_SIZE" in c3:
-    traffic["fft_accum_c3_fetch_bytes_per_launch"] = c3["FETCH_SIZE"] * 1024.0 * 2.0
-    traffic["fft_accum_c3_write_bytes_per_launch"] = c3["WRITE_SIZE"] * 1024.0
-    traffic["fft_accum_c3_hbm_bytes_per_launch"] = (traffic["fft_accum_c3_fetch_bytes_per_launch"] +
-                                                    traffic["fft_accum_c3_write_bytes_per_launch"])
-    json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
-    out["K1_fft_accum_C3_windowed"] = c3
-for name in ("c3_trace/c3_kernel_stats.csv", "c3_bench.json", "c4_trace/c4_kernel_stats.csv", "c4.json"):
-    pth = os.path.join(src, name)
-    if os.path.exists(pth):
-        shutil.copy(pth, os.path.join(dst, tag + "_" + os.path.basename(name)))
+# C4: one acquisition = 8 batches of the column and row kernels
+c4 = {}
+for sub in ("c4_pmc_FETCH_SIZE", "c4_pmc_WRITE_SIZE"):
+    m, tot = means(rows_of(sub, "c4"), full_grid_only=False)
+    for k, d in m.items():
+        c4.setdefault(k, {}).update(d)
+    for k, d in tot.items():
+        for c, (s, n) in d.items():
+            c4.setdefault(k + "_totals", {})[c] = {"sum_KiB": s, "launches": n}
+out["C4_fourstep"] = c4
+try:
+    acq = c4["K2b_rows_totals"]["FETCH_SIZE"]["launches"] / 8.0
+    fetch = (c4["K2a_cols_totals"]["FETCH_SIZE"]["sum_KiB"] + c4["K2b_rows_totals"]["FETCH_SIZE"]["sum_KiB"]) * 1024.0 * 2.0 / acq
+    acq_w = c4["K2b_rows_totals"]["WRITE_SIZE"]["launches"] / 8.0
+    write = (c4["K2a_cols_totals"]["WRITE_SIZE"]["sum_KiB"] + c4["K2b_rows_totals"]["WRITE_SIZE"]["sum_KiB"]) * 1024.0 / acq_w
+    traffic["fourstep_c4_fetch_bytes_per_launch"] = fetch
+    traffic["fourstep_c4_write_bytes_per_launch"] = write
+    traffic["fourstep_c4_hbm_bytes_per_launch"] = fetch + write
+    traffic["fourstep_c4_note"] = "per acquisition of 1000 frames = 8 batches of K2a + K2b; the intermediate Y is written and read once"
+except (KeyError, ZeroDivisionError):
+    pass
+
+hb = os.path.join(src, "hbm_read.txt")
+if os.path.exists(hb):            # tools/hbm_read_bench.hip: read-only stream > Infinity Cache
+    m = re.search(r"read-only stream of (\d+) B: .* = (\d+) GB/s", open(hb).read())
+    if m:
+        traffic["measured_read_only_GBps"] = float(m.group(2))
+        traffic["measured_read_only_bytes"] = int(m.group(1))
+json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+
+lv = os.path.join(src, "lds_valu.txt")
+if os.path.exists(lv):            # sustained packed-f32 rate: mode 0 at 4 waves per SIMD
+    m = re.search(r"mode 0 .*x4/CU \(4 waves/SIMD\):\s+([\d.]+) ns per iteration", open(lv).read())
+    if m:
+        ns = float(m.group(1))
+        json.dump({"captured": captured, "pk_fma_ns_per_instruction_per_simd": ns / 4.0 / 320.0,
+                   "source": "tools/lds_valu_bench mode 0 (320 v_pk_fma_f32 per wave and iteration, 4 waves per SIMD, "
+                             "every CU busy): %.1f ns per iteration" % ns,
+                   "equivalent_clock_GHz_at_4_cycles_per_instruction": 4.0 / (ns / 4.0 / 320.0)},
+                  open(os.path.join(dst, "valu_rate.json"), "w"), indent=1)
+
 json.dump(out, open(os.path.join(dst, tag + "_counters.json"), "w"), indent=1)
-print(json.dumps(out, indent=1))
 print(json.dumps(traffic, indent=1))
