@@ -297,9 +297,11 @@ def main():
     # on a ring of blocks so that it overlaps the following steps' kernels.
     rows = hops if strong else 8
     nring = 4
-    d_pwr = [torch.zeros(rows, N, dtype=torch.float64, device=dev) for _ in range(nring)]
+    # (strong scaling: rank 0 owns only some rows of a block and must clear the others before reuse;
+    # weak scaling: every rank rewrites every row, nothing to clear)
+    ring = rpf.sharding.ScanRing(rows, N, dev, nring=nring, dst=0, enabled=use_dist, clear_on_reuse=strong)
+    d_pwr = ring.blocks
     s = torch.cuda.current_stream().cuda_stream
-    pending = [None] * nring
 
     def step(i, ev=None):
         if strong:
@@ -308,9 +310,8 @@ def main():
         else:
             blk, row = (i // rows) % nring, i % rows
             new_block, last_of_block = row == 0, row == rows - 1
-        if new_block and pending[blk] is not None:
-            pending[blk].wait()
-            pending[blk] = None
+        if new_block:
+            ring.begin(blk)
         streams = bufs[i % nb]
         for k, (hop, first, count) in enumerate(mine):
             out_row = d_pwr[blk][hop if strong else row]
@@ -320,22 +321,16 @@ def main():
             if ev is not None and k == 0:
                 ev[1].record()
             ds.device_reduce(out_row.data_ptr(), s)
-        if use_dist and last_of_block:
-            pending[blk] = dist.reduce(d_pwr[blk], dst=0, op=dist.ReduceOp.SUM, async_op=True)
+        if last_of_block:
+            ring.submit(blk)
         return blk
-
-    def drain():
-        for k in range(nring):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
 
     def fence(last_step=None):
         # a block of acquisitions cut short by the step count still owes its (partial) reduce
         if use_dist and not strong and last_step is not None and last_step % rows != rows - 1:
             blk = (last_step // rows) % nring
-            dist.reduce(d_pwr[blk], dst=0, op=dist.ReduceOp.SUM)
-        drain()
+            ring.submit(blk, async_op=False)
+        ring.drain()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()

@@ -40,3 +40,53 @@ def reduce_power(pwr, dst=0, group=None, async_op=False):
     """Sum per-bin accumulators onto rank `dst` (torch tensor, any backend)."""
     import torch.distributed as dist
     return dist.reduce(pwr, dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+class ScanRing:
+    """The exchange step of a sharded scan: a ring of blocks of `rows` x N
+    double accumulators.  A rank fills the rows it owns of block k (its kernels write them),
+    `submit(k)` starts ONE asynchronous reduce of the whole block onto rank `dst` -- fewer,
+    larger collectives -- and the ring lets that reduce overlap the next scans' kernels;
+    `begin(k)` is called before a block is written again: it waits for the block's previous
+    reduce and, on `dst`, clears the block -- after a reduce `dst` holds the SUM, and the rows
+    it does not own would otherwise be counted again next time round.
+
+    Works on any torch device / backend (RCCL on GPUs in bench.py, gloo on CPU in the tests)."""
+
+    def __init__(self, rows, N, device, nring=4, dst=0, enabled=True, clear_on_reuse=True):
+        import torch
+        self.blocks = [torch.zeros(rows, N, dtype=torch.float64, device=device) for _ in range(nring)]
+        self.pending = [None] * nring
+        self.used = [False] * nring
+        self.dst = dst
+        self.enabled = enabled
+        self.clear_on_reuse = clear_on_reuse
+
+    def __len__(self):
+        return len(self.blocks)
+
+    def begin(self, k):
+        """Block k is about to be written for a new scan."""
+        if self.pending[k] is not None:
+            self.pending[k].wait()
+            self.pending[k] = None
+        if self.enabled and self.clear_on_reuse and self.used[k]:
+            import torch.distributed as dist
+            if dist.get_rank() == self.dst:
+                self.blocks[k].zero_()
+        self.used[k] = True
+        return self.blocks[k]
+
+    def submit(self, k, async_op=True):
+        """All of this rank's rows of block k are written (or enqueued on the current stream)."""
+        if not self.enabled:
+            return None
+        w = reduce_power(self.blocks[k], dst=self.dst, async_op=async_op)
+        self.pending[k] = w if async_op else None
+        return w
+
+    def drain(self):
+        for k in range(len(self.blocks)):
+            if self.pending[k] is not None:
+                self.pending[k].wait()
+                self.pending[k] = None
