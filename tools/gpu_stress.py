@@ -21,15 +21,22 @@ ncase = 0
 worst = 0.0
 worst_case = None
 while time.time() - t0 < budget:
-    fam = rng.integers(0, 4)
-    if fam == 0:
+    fam = rng.integers(0, 10)
+    flags = 0
+    if fam < 2:
         N = int(rng.choice(POW2))
-    elif fam == 1:
+    elif fam < 5:
         N = int(rng.choice(FOUR))
-    elif fam == 2:
+        if rng.integers(0, 2):
+            flags = rpf._lib.FLAG_FOURSTEP_FUSED          # the fused persistent kernel (teams, barriers)
+    elif fam < 7:
         N = 2 * int(rng.integers(1, 2049))
-    else:
+    elif fam < 9:
         N = 2 * int(rng.integers(2049, 65536))
+    else:                                                 # catch-all path
+        N = int(rng.choice([524288, 2 * int(rng.integers(65537, 200000))]))
+    if rng.integers(0, 5) == 0:
+        flags |= rpf._lib.FLAG_NO_LDS_DMA
     if rpf.load().rpf_supported_n(N) != 1:
         continue
     max_frames = max(2, min(3000, (24 << 20) // (2 * N)))
@@ -47,7 +54,7 @@ while time.time() - t0 < budget:
     outs = []
     params = rpf.Params(N=N, window=windowed, repeats=quota, **({"buf_length": buf_len} if buf_len else {}))
     try:
-        with rpf.Datastore(params, w) as ds:
+        with rpf.Datastore(params, w, flags=flags) as ds:
             for rep in range(3):
                 d_out = torch.full((N,), float("nan"), dtype=torch.float64, device=dev)
                 n = ds.accumulate_device(d_in.data_ptr(), stream.size, quota, d_out.data_ptr(),
@@ -66,7 +73,7 @@ while time.time() - t0 < budget:
                 host, done = ds.accumulate(stream, quota)
                 assert done == quota
     except Exception as ex:
-        print("FAIL N=%d R=%d quota=%d win=%d off=%d buf=%s: %r" % (N, R, quota, windowed, offset, buf_len, ex), flush=True)
+        print("FAIL N=%d R=%d quota=%d win=%d off=%d buf=%s flags=%d: %r" % (N, R, quota, windowed, offset, buf_len, flags, ex), flush=True)
         sys.exit(1)
     truth = truth_f64(N, stream, quota, w)
     err = max_err_over_mean(outs[0], truth)
@@ -79,8 +86,8 @@ while time.time() - t0 < budget:
         ok = ok and float(np.max(np.abs(host - outs[0]) / np.maximum(np.abs(outs[0]), 1e-300))) < 1e-12
     ncase += 1
     if not ok:
-        print("FAIL N=%d R=%d quota=%d win=%d off=%d buf=%s err=%.3e same=%s/%s" % (
-            N, R, quota, windowed, offset, buf_len, err, np.array_equal(outs[0], outs[1]), np.array_equal(outs[0], outs[2])), flush=True)
+        print("FAIL N=%d R=%d quota=%d win=%d off=%d buf=%s flags=%d err=%.3e same=%s/%s" % (
+            N, R, quota, windowed, offset, buf_len, flags, err, np.array_equal(outs[0], outs[1]), np.array_equal(outs[0], outs[2])), flush=True)
         sys.exit(1)
 print("stress: %d cases in %.0f s, worst error over mean bin %.2e at (N, frames, quota, windowed) = %s: all within bounds"
       % (ncase, time.time() - t0, worst, worst_case))
