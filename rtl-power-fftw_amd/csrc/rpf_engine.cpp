@@ -89,6 +89,7 @@ struct rpf_engine {
     void* d_fused_ctl = nullptr;          // its team counters / abort flag
     bool bluestein = false;               // N handled by the Bluestein kernel (chirp tables below)
     bool bigblu = false;                  // N handled by the large (four-step) Bluestein path
+    bool mixed = false;                   // N handled by the LDS mixed-radix kernel (rpf_mixed.hip)
     bool generic = false;                 // N handled by the catch-all Stockham path (rpf_generic.hip)
     int gen_h = 0;                        // its two-level twiddle split (d_tw_sub = T0, d_tw_sub2 = T1)
     int blu_M = 0;                        // bigblu: convolution length (partial spectra have M entries)
@@ -193,6 +194,12 @@ int launch_transform(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, hi
     }
     const int64_t wanted = (nframes + e->plan.fpw - 1) / e->plan.fpw;
     const int grid = static_cast<int>(std::min<int64_t>(e->plan.grid, wanted));
+    if (e->mixed) {
+        HIP_TRY(e, rpf::launch_mixed(e->N, d_frames, nframes, e->d_twiddles, e->d_window, e->d_partial, grid, stream,
+                                     &e->last));
+        *nslots = grid;
+        return RPF_OK;
+    }
     if (e->bluestein) {
         HIP_TRY(e, rpf::launch_bluestein(e->N, d_frames, nframes, e->d_twiddles, e->d_chirp, e->d_bhat,
                                          e->d_partial, grid, stream, &e->last));
@@ -392,7 +399,7 @@ int rpf_abi_version(void) { return RPF_ABI_VERSION; }
 
 int rpf_supported_n(int N)
 {
-    return (rpf::kernel_supported(N) || rpf::fourstep_supported(N) || rpf::bluestein_supported(N) ||
+    return (rpf::kernel_supported(N) || rpf::fourstep_supported(N) || rpf::mixed_supported(N) || rpf::bluestein_supported(N) ||
             rpf::bigblu_supported(N) || rpf::generic_supported(N)) ? 1 : 0;
 }
 
@@ -409,9 +416,10 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
                     "Number of bins must be a positive even number.");
     const int variant = static_cast<int>((cfg->flags >> 8) & 0xffu);
     const bool fourstep = rpf::fourstep_supported(cfg->N) && variant == 0;
-    const bool bluestein = rpf::bluestein_supported(cfg->N) && variant == 0;
+    const bool mixed = rpf::mixed_supported(cfg->N) && variant == 0 && !(cfg->flags & RPF_FLAG_NO_MIXED_RADIX);
+    const bool bluestein = !mixed && rpf::bluestein_supported(cfg->N) && variant == 0;
     const bool bigblu = rpf::bigblu_supported(cfg->N) && variant == 0;
-    const bool tuned = fourstep || bluestein || bigblu || rpf::kernel_supported(cfg->N, variant);
+    const bool tuned = fourstep || mixed || bluestein || bigblu || rpf::kernel_supported(cfg->N, variant);
     const bool generic = !tuned && variant == 0 && rpf::generic_supported(cfg->N);
     if (!tuned && !generic)
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT,
@@ -442,6 +450,7 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
     e->use_dma = !(cfg->flags & RPF_FLAG_NO_LDS_DMA);
     e->variant = variant;
     e->fourstep = fourstep;
+    e->mixed = mixed;
     e->bluestein = bluestein;
     e->bigblu = bigblu;
     e->generic = generic;
@@ -505,6 +514,9 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         e->plan.fpw = rpf::generic_batch(e->N);
         e->plan.lds_bytes = 0;
         partial_slots = 1;
+    } else if (e->mixed) {
+        CREATE_TRY(rpf::plan_mixed(e->N, e->device, &e->plan));
+        partial_slots = e->plan.grid;
     } else if (e->bluestein) {
         CREATE_TRY(rpf::plan_bluestein(e->N, e->device, &e->plan));
         partial_slots = e->plan.grid;

@@ -123,6 +123,30 @@ def test_non_power_of_two_sizes_match_oracle(N, windowed, torch_dev):
     assert max_rel(host, got) < 1e-13
 
 
+@pytest.mark.parametrize("N", [6, 10, 12, 90, 250, 500, 600, 1000, 1200, 1500, 2000, 2430, 3000, 3600, 3750, 4000, 4050])
+def test_mixed_radix_sizes_match_oracle_and_bluestein(N, torch_dev):
+    """Even N <= 4096 with prime factors 2, 3, 5 only (the "round" sizes, the man page's -b 500
+    among them): LDS mixed-radix kernel (rpf_mixed.hip) against the float32 oracle, float64
+    truth, and the Bluestein kernel it replaces for these sizes; device and queue paths."""
+    R = 53
+    stream = rpf.synth.uniform_iq(400 + N, N * R + N)
+    for windowed in (False, True):
+        w = rpf.synth.hann_window(N) + np.float32(0.25) if windowed else None
+        with rpf.Datastore(rpf.Params(N=N, window=windowed, repeats=R, buf_length=16384), w) as ds:
+            got, n = run_device(ds, stream, R, torch_dev)
+            again, _ = run_device(ds, stream, R, torch_dev)
+            host, done = ds.accumulate(stream, R)          # 16 KB buffers: frames straddle them
+        with rpf.Datastore(rpf.Params(N=N, window=windowed, repeats=R), w,
+                           flags=rpf._lib.FLAG_NO_MIXED_RADIX) as blu:
+            other, _ = run_device(blu, stream, R, torch_dev)
+        assert n == done == R and np.array_equal(got, again)
+        assert max_rel(host, got) < 1e-13
+        o32, _ = oracle_accumulate(N, stream, R, w, 32)
+        assert max_rel(got, o32) < PARITY
+        assert max_rel(got, truth_f64(N, stream, R, w)) < VS_TRUTH
+        assert max_rel(got, other) < PARITY
+
+
 @pytest.mark.parametrize("N", [16384, 32768, 65536, 131072, 262144])
 def test_four_step_sizes_match_oracle(N, torch_dev):
     """Powers of two beyond one workgroup's LDS (rpf_fourstep.hip; 262144 is config
