@@ -232,6 +232,15 @@ constexpr int threads_per_frame_c(int N)
     return tpf;
 }
 
+// the twiddle table sits in LDS unless leaving it in HBM/L1 lets one more workgroup onto the CU
+// (measured: N = 3000 158 -> 240 Gsample/s without it, N = 4000 171 -> 114)
+constexpr bool spec_tw_in_lds(int N)
+{
+    const int slots = kMixedWG / threads_per_frame_c(N);
+    const int base = slots * N * (2 * (int)sizeof(cf) + (int)sizeof(double));
+    return (160 * 1024) / (base + N * (int)sizeof(cf)) >= (160 * 1024) / base;
+}
+
 template <int N, int TPF, int S, bool FIRST, int R, int... Rest>
 __device__ __forceinline__ void spec_passes(cf* src, cf* dst, const uint8_t* frame, const float* window, const cf* tw,
                                             double* acc, bool active, int t)
@@ -258,9 +267,12 @@ __global__ __launch_bounds__(kMixedWG) void mixed_spec_kernel(const uint8_t* __r
     cf* const bufB = bufA + N;
     double* const acc_all = reinterpret_cast<double*>(smem + FPW * 2 * N * sizeof(cf));
     double* const acc = acc_all + fs * N;
-    cf* const tw = reinterpret_cast<cf*>(acc_all + FPW * N);
+    constexpr bool TWLDS = spec_tw_in_lds(N);
+    cf* const twl = reinterpret_cast<cf*>(acc_all + FPW * N);
+    const cf* const tw = TWLDS ? twl : twN;
     for (int bin = t; bin < N; bin += TPF) acc[bin] = 0.0;
-    for (int k = tid; k < N; k += kMixedWG) tw[k] = twN[k];
+    if constexpr (TWLDS)
+        for (int k = tid; k < N; k += kMixedWG) twl[k] = twN[k];
     __syncthreads();
     const long stride = static_cast<long>(gridDim.x) * FPW;
 #pragma unroll 1
@@ -325,9 +337,11 @@ int threads_per_frame(int N)
     return tpf;
 }
 
-int lds_bytes(int N)       // [frame slots][2 buffers + accumulators] + the twiddle table
+int lds_bytes(int N)       // [frame slots][2 buffers + accumulators] (+ the twiddle table)
 {
-    return (kMixedWG / threads_per_frame(N)) * N * (2 * (int)sizeof(cf) + (int)sizeof(double)) + N * (int)sizeof(cf);
+    const bool table = !find_spec(N) || spec_tw_in_lds(N);
+    return (kMixedWG / threads_per_frame(N)) * N * (2 * (int)sizeof(cf) + (int)sizeof(double)) +
+           (table ? N * (int)sizeof(cf) : 0);
 }
 
 }  // namespace
