@@ -418,7 +418,7 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
     const bool fourstep = rpf::fourstep_supported(cfg->N) && variant == 0;
     const bool mixed = rpf::mixed_supported(cfg->N) && variant == 0 && !(cfg->flags & RPF_FLAG_NO_MIXED_RADIX);
     const bool bluestein = !mixed && rpf::bluestein_supported(cfg->N) && variant == 0;
-    const bool bigblu = rpf::bigblu_supported(cfg->N) && variant == 0;
+    const bool bigblu = !mixed && rpf::bigblu_supported(cfg->N) && variant == 0;
     const bool tuned = fourstep || mixed || bluestein || bigblu || rpf::kernel_supported(cfg->N, variant);
     const bool generic = !tuned && variant == 0 && rpf::generic_supported(cfg->N);
     if (!tuned && !generic)

@@ -40,7 +40,7 @@ hipError_t launch_fft_accum(int N, int vid, bool window, bool use_dma, const uin
 hipError_t launch_reduce(const double* d_partial, int nslots, int N, double* d_out,
                          bool accumulate, hipStream_t stream, bool partial_f32 = false, size_t slot_stride = 0);
 
-// ---- mixed-radix path (KM, rpf_mixed.hip): even N <= 4096 with prime factors 2, 3, 5 only, not a power of two --
+// ---- mixed-radix path (KM, rpf_mixed.hip): even N <= 5120 (6400 for the specialised sizes) with prime factors 2, 3, 5 only, not a power of two --
 bool mixed_supported(int N);
 hipError_t plan_mixed(int N, int device, LaunchInfo* li);
 // d_twN: master twiddles W_N^k; one partial spectrum of N doubles per workgroup

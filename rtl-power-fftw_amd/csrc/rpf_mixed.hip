@@ -307,7 +307,9 @@ const SpecEntry kSpec[] = {
     {2000, mixed_spec_kernel<2000, 5, 5, 5, 4, 4>},    {2400, mixed_spec_kernel<2400, 5, 5, 4, 4, 3, 2>},
     {2500, mixed_spec_kernel<2500, 5, 5, 5, 5, 4>},    {3000, mixed_spec_kernel<3000, 5, 5, 5, 4, 3, 2>},
     {3200, mixed_spec_kernel<3200, 5, 5, 4, 4, 4, 2>}, {3600, mixed_spec_kernel<3600, 5, 5, 4, 4, 3, 3>},
-    {4000, mixed_spec_kernel<4000, 5, 5, 5, 4, 4, 2>},
+    {4000, mixed_spec_kernel<4000, 5, 5, 5, 4, 4, 2>}, {4800, mixed_spec_kernel<4800, 5, 5, 4, 4, 4, 3>},
+    {5000, mixed_spec_kernel<5000, 5, 5, 5, 5, 4, 2>}, {6000, mixed_spec_kernel<6000, 5, 5, 5, 4, 4, 3>},
+    {6400, mixed_spec_kernel<6400, 5, 5, 4, 4, 4, 4>},
 };
 const SpecEntry* find_spec(int N)
 {
@@ -346,10 +348,12 @@ int lds_bytes(int N)       // [frame slots][2 buffers + accumulators] (+ the twi
 
 }  // namespace
 
-// even N <= 4096, only prime factors 2, 3, 5, not a power of two (those are K1's)
+// even N whose frame (two buffers + accumulators [+ twiddles]) fits one workgroup's LDS -- up to 5120
+// bins for any such size, 6400 for the specialised ones --, only prime factors 2, 3, 5, not a power
+// of two (those are K1's)
 bool mixed_supported(int N)
 {
-    if (N < 2 || (N & 1) || N > 4096 || (N & (N - 1)) == 0) return false;
+    if (N < 2 || (N & 1) || N > 6400 || (N & (N - 1)) == 0) return false;
     MixedPlan plan;
     return factorise(N, &plan) && lds_bytes(N) <= 160 * 1024;
 }

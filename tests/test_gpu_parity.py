@@ -123,7 +123,8 @@ def test_non_power_of_two_sizes_match_oracle(N, windowed, torch_dev):
     assert max_rel(host, got) < 1e-13
 
 
-@pytest.mark.parametrize("N", [6, 10, 12, 90, 250, 500, 600, 1000, 1200, 1500, 2000, 2430, 3000, 3600, 3750, 4000, 4050])
+@pytest.mark.parametrize("N", [6, 10, 12, 90, 250, 500, 600, 1000, 1200, 1500, 2000, 2430, 3000, 3600, 3750, 4000, 4050,
+                               4500, 5000, 5120 - 120, 6000, 6400])
 def test_mixed_radix_sizes_match_oracle_and_bluestein(N, torch_dev):
     """Even N <= 4096 with prime factors 2, 3, 5 only (the "round" sizes, the man page's -b 500
     among them): LDS mixed-radix kernel (rpf_mixed.hip) against the float32 oracle, float64
