@@ -278,6 +278,18 @@ RPF_HD cf iq_plus_2p23(uint32_t iq)
     return cf{byte_plus_2p23(iq & 0xffu), byte_plus_2p23((iq >> 8) & 0xffu)};
 #endif
 }
+// the same for sample h (0 or 1) of a register that holds two interleaved samples, I0 Q0 I1 Q1
+template <int H>
+RPF_HD cf iq_pair_plus_2p23(uint32_t iq2)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t bi = __builtin_amdgcn_perm(0x4B000000u, iq2, H ? 0x070c0c02u : 0x070c0c00u);
+    const uint32_t bq = __builtin_amdgcn_perm(0x4B000000u, iq2, H ? 0x070c0c03u : 0x070c0c01u);
+    return cf{__builtin_bit_cast(float, bi), __builtin_bit_cast(float, bq)};
+#else
+    return iq_plus_2p23(H ? iq2 >> 16 : iq2 & 0xffffu);
+#endif
+}
 constexpr float kTwo23 = 8388608.0f;
 
 // Raw-byte staging is wavefront-local: a wave stages exactly the samples its own

@@ -1,0 +1,197 @@
+// mixed_core.h -- per-thread building blocks of KM, the LDS-resident mixed-radix kernel
+// (rpf_mixed.hip): K1's scheme (fft_core.h) carried over to lengths N = R_0 R_1 ... R_{F-1} whose
+// radices are the small composites of dft_small.h (2 ... 25).
+//
+// Decimation in frequency, in place by element name e in [0, N) (= the time index n in pass 0):
+// with S_i = R_{i+1} ... R_{F-1} and D_i = R_0 ... R_{i-1}, pass i runs N / R_i butterflies
+//
+//   b = khead S_i + ntail   (khead < D_i, ntail < S_i)    elements  e_n = khead R_i S_i + n S_i + ntail
+//   v <- DFT_{R_i}(v);   v[k] *= W_N^{D_i ntail k}   (no twiddles in the last pass: S = 1)
+//
+// and the value that ends in element e = sum_i k_i S_i is X[sum_i k_i D_i] (digit reversal in the
+// mixed radix system; free, because the only consumer is a per-bin accumulator that lives
+// wherever its bin lands).  A thread owns G_i butterflies of pass i -- b = t + g TPF_i,
+// TPF_i = N / (R_i G_i) threads of the frame take part in pass i -- and the SAME butterflies in
+// every frame, so its twiddles are loop-invariant registers (or a per-thread row of an LDS table)
+// and its accumulators never move.  Between passes the frame goes through one padded LDS slab:
+// slot(e) = e + e / R_last keeps the last pass's stride-R_last fetch off the same banks, and
+// because every S_i (i < F-1) is a multiple of R_last the slot of e_n is slot(e_0) plus a
+// compile-time constant -- the DS instruction's immediate offset.
+// Plain C++17 on registers and pointers: compiled by hipcc into the gfx950 kernel and by the host
+// emulator under tests/emul that checks the index maps thread by thread without a GPU.
+#pragma once
+
+#include "dft_small.h"
+
+namespace rpf {
+
+template <int R_, int G_ = 1>
+struct MPass {
+    static constexpr int R = R_, G = G_;
+};
+
+// TW: where a thread's twiddles live -- 0 registers, 1 per-thread rows of an LDS table.
+template <int N_, int FPW_, int TW_, class... Ps>
+struct MixPlan {
+    static constexpr int N = N_, FPW = FPW_, TW = TW_;
+    static constexpr int F = sizeof...(Ps);
+    static constexpr int Rs[F] = {Ps::R...};
+    static constexpr int Gs[F] = {Ps::G...};
+    static constexpr int R(int i) { return Rs[i]; }
+    static constexpr int G(int i) { return Gs[i]; }
+    static constexpr int S(int i)        // product of the later radices
+    {
+        int s = 1;
+        for (int j = i + 1; j < F; ++j) s *= Rs[j];
+        return s;
+    }
+    static constexpr int D(int i)        // product of the earlier radices
+    {
+        int d = 1;
+        for (int j = 0; j < i; ++j) d *= Rs[j];
+        return d;
+    }
+    static constexpr int TPF(int i) { return N / (Rs[i] * Gs[i]); }
+    static constexpr int tpf_max()
+    {
+        int m = 0;
+        for (int i = 0; i < F; ++i) m = TPF(i) > m ? TPF(i) : m;
+        return m;
+    }
+    static constexpr int TPFMAX = tpf_max();
+    static constexpr int WG = FPW * TPFMAX;
+    static constexpr int RLAST = Rs[F - 1];
+    static constexpr bool PAD = (RLAST % 2) == 0;      // an odd stride is conflict-free as it is
+    static RPF_HD int slot(int e) { return PAD ? e + e / RLAST : e; }
+    static constexpr int LDS_CPX = PAD ? N + N / RLAST : N;
+    static constexpr int tw_offset(int i)     // first twiddle of pass i in a thread's list
+    {
+        int o = 0;
+        for (int j = 0; j < i; ++j) o += Gs[j] * (Rs[j] - 1);
+        return o;
+    }
+    static constexpr int NTW = tw_offset(F - 1);
+    static constexpr int tw_table_offset(int i)   // first entry of pass i's block of the LDS table
+    {
+        int o = 0;
+        for (int j = 0; j < i; ++j) o += Gs[j] * (Rs[j] - 1) * TPF(j);
+        return o;
+    }
+    static constexpr int TW_TABLE = tw_table_offset(F - 1);
+    static constexpr int PPT0 = Rs[0] * Gs[0];
+    static constexpr int NRAW = (PPT0 + 1) / 2;          // raw registers: two samples each
+    static constexpr int LDS_BYTES = (FPW * LDS_CPX + (TW == 1 ? TW_TABLE : 0)) * 8;
+    // window values: the thread's registers, or (room permitting) LDS when it has many of them or few registers
+    static constexpr bool WLDS = LDS_BYTES + 4 * N <= 160 * 1024;
+    static constexpr int PPTL = Rs[F - 1] * Gs[F - 1];
+    static constexpr bool valid()
+    {
+        int p = 1;
+        for (int i = 0; i < F; ++i) {
+            p *= Rs[i];
+            if (N % (Rs[i] * Gs[i]) != 0) return false;
+        }
+        return p == N && F >= 2;
+    }
+    static_assert(valid(), "radices must multiply to N and R_i G_i must divide N");
+};
+
+// slot of register 0 of butterfly g of thread t in pass I, and the constant added for register n
+template <class PL, int I>
+RPF_HD int mix_slot_base(int t, int g)
+{
+    constexpr int S = PL::S(I), R = PL::R(I);
+    const int b = t + g * PL::TPF(I);
+    const int khead = b / S, ntail = b - khead * S;
+    return PL::slot(khead * R * S + ntail);
+}
+template <class PL, int I>
+constexpr int mix_slot_delta(int n)
+{
+    return n * PL::S(I) + (PL::PAD ? (n * PL::S(I)) / PL::RLAST : 0);
+}
+// index into the master table W_N^k of the twiddle of output k of butterfly g (pass I < F-1)
+template <class PL, int I>
+RPF_HD int mix_twiddle_index(int t, int g, int k)
+{
+    const int b = t + g * PL::TPF(I);
+    return PL::D(I) * (b % PL::S(I)) * k;
+}
+// time index of input n1 of butterfly g of pass 0
+template <class PL>
+RPF_HD int mix_sample_index(int t, int g, int n1)
+{
+    return n1 * PL::S(0) + t + g * PL::TPF(0);
+}
+// spectrum bin of output k of butterfly g of the last pass
+template <class PL, int I = PL::F - 2>
+RPF_HD int mix_bin_head(int khead)
+{
+    // khead = ((k_0 R_1 + k_1) R_2 + ...) + k_{F-2}: peel the digits from the least significant
+    if constexpr (I >= 0) {
+        const int q = khead / PL::R(I), k = khead - q * PL::R(I);
+        return k * PL::D(I) + mix_bin_head<PL, I - 1>(q);
+    } else {
+        return 0;
+    }
+}
+template <class PL>
+RPF_HD int mix_bin(int t, int g, int k)
+{
+    return mix_bin_head<PL>(t + g * PL::TPF(PL::F - 1)) + k * PL::D(PL::F - 1);
+}
+
+// Pass 0, butterfly g: unpack R_0 samples (datastore.cxx:73-77) from the thread's raw registers,
+// two 16-bit samples per register (sample n1 of butterfly g = half (g R_0 + n1) & 1 of register
+// (g R_0 + n1) / 2).  sgn = (-1)^(t + g TPF_0); wsgn[n1] = window * (-1)^n of the same samples.
+// WSTRIDE: distance between the window values of consecutive n1 (1: the thread's registers; S_0: the
+// workgroup's LDS copy of window[n] (-1)^n, used when the registers are needed elsewhere).
+template <class PL, bool WINDOW, int GOFF, int WSTRIDE = 1, int N1 = 0>
+RPF_HD void mix_unpack(const uint32_t* raw, float sgn, const float* wsgn, cf* v)
+{
+    if constexpr (N1 < PL::R(0)) {
+        constexpr int idx = GOFF + N1;
+        const cf f = iq_pair_plus_2p23<idx & 1>(raw[idx >> 1]);
+        if constexpr (WINDOW) {
+            v[N1] = (f - (kTwo23 + 127.0f)) * wsgn[N1 * WSTRIDE];      // (v - 127) exact, one rounding
+        } else {
+            const float sg = ((N1 * PL::S(0)) & 1) ? -sgn : sgn;       // (-1)^(n1 S_0 + ntail)
+            v[N1] = f * sg - (kTwo23 + 127.0f) * sg;                   // every step exact
+        }
+        mix_unpack<PL, WINDOW, GOFF, WSTRIDE, N1 + 1>(raw, sgn, wsgn, v);
+    }
+}
+
+template <class PL, int I>
+RPF_HD void mix_butterfly(cf* v, const cf* tw)
+{
+    constexpr int R = PL::R(I);
+    SmallDft<R>::run(v);
+    if constexpr (I < PL::F - 1) {
+#pragma unroll
+        for (int k = 1; k < R; ++k) v[k] = cmul(v[k], tw[k - 1]);
+    }
+}
+
+template <class PL, int I>
+RPF_HD void mix_store(int slot_base, const cf* v, cf* slab)
+{
+    cf* const p = slab + slot_base;
+#pragma unroll
+    for (int n = 0; n < PL::R(I); ++n) p[mix_slot_delta<PL, I>(n)] = v[n];
+}
+template <class PL, int I>
+RPF_HD void mix_fetch(int slot_base, cf* v, const cf* slab)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (volatile LDS pointer: keeps hipcc from pairing the loads into the half-rate ds_read2_b64)
+    using lds_cf = const volatile __attribute__((address_space(3))) cf;
+    lds_cf* const p = (lds_cf*)(slab + slot_base);
+#else
+    const cf* const p = slab + slot_base;
+#endif
+#pragma unroll
+    for (int n = 0; n < PL::R(I); ++n) v[n] = p[mix_slot_delta<PL, I>(n)];
+}
+
+}  // namespace rpf

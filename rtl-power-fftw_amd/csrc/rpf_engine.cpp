@@ -195,7 +195,7 @@ int launch_transform(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, hi
     const int64_t wanted = (nframes + e->plan.fpw - 1) / e->plan.fpw;
     const int grid = static_cast<int>(std::min<int64_t>(e->plan.grid, wanted));
     if (e->mixed) {
-        HIP_TRY(e, rpf::launch_mixed(e->N, d_frames, nframes, e->d_twiddles, e->d_window, e->d_partial, grid, stream,
+        HIP_TRY(e, rpf::launch_mixed(e->N, e->variant, d_frames, nframes, e->d_twiddles, e->d_window, e->d_partial, grid, stream,
                                      &e->last));
         *nslots = grid;
         return RPF_OK;
@@ -416,7 +416,7 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
                     "Number of bins must be a positive even number.");
     const int variant = static_cast<int>((cfg->flags >> 8) & 0xffu);
     const bool fourstep = rpf::fourstep_supported(cfg->N) && variant == 0;
-    const bool mixed = rpf::mixed_supported(cfg->N) && variant == 0 && !(cfg->flags & RPF_FLAG_NO_MIXED_RADIX);
+    const bool mixed = rpf::mixed_supported(cfg->N, variant) && !(cfg->flags & RPF_FLAG_NO_MIXED_RADIX);
     const bool bluestein = !mixed && rpf::bluestein_supported(cfg->N) && variant == 0;
     const bool bigblu = !mixed && rpf::bigblu_supported(cfg->N) && variant == 0;
     const bool tuned = fourstep || mixed || bluestein || bigblu || rpf::kernel_supported(cfg->N, variant);
@@ -465,9 +465,11 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
 #define CREATE_TRY(call)                                                                 \
     do {                                                                                 \
         hipError_t err__ = (call);                                                       \
-        if (err__ != hipSuccess)                                                         \
+        if (err__ != hipSuccess) {                                                       \
+            (void)hipGetLastError();     /* not the caller's next HIP call's problem */  \
             return cleanup(fail(nullptr, RPF_ERR_HARDWARE,                               \
                                 std::string(#call) + ": " + hipGetErrorString(err__)));  \
+        }                                                                                \
     } while (0)
 
     DeviceScope on_device(e->device);       // the caller's current device is restored on return
@@ -515,7 +517,7 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         e->plan.lds_bytes = 0;
         partial_slots = 1;
     } else if (e->mixed) {
-        CREATE_TRY(rpf::plan_mixed(e->N, e->device, &e->plan));
+        CREATE_TRY(rpf::plan_mixed(e->N, e->variant, e->has_window, e->device, &e->plan));
         partial_slots = e->plan.grid;
     } else if (e->bluestein) {
         CREATE_TRY(rpf::plan_bluestein(e->N, e->device, &e->plan));

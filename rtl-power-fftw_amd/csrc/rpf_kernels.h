@@ -41,10 +41,11 @@ hipError_t launch_reduce(const double* d_partial, int nslots, int N, double* d_o
                          bool accumulate, hipStream_t stream, bool partial_f32 = false, size_t slot_stride = 0);
 
 // ---- mixed-radix path (KM, rpf_mixed.hip): even N <= 5120 (6400 for the specialised sizes) with prime factors 2, 3, 5 only, not a power of two --
-bool mixed_supported(int N);
-hipError_t plan_mixed(int N, int device, LaunchInfo* li);
+// variant: 0 = the shipped kernel of the size; others (tuning build only) = alternative plans
+bool mixed_supported(int N, int variant = 0);
+hipError_t plan_mixed(int N, int variant, bool windowed, int device, LaunchInfo* li);
 // d_twN: master twiddles W_N^k; one partial spectrum of N doubles per workgroup
-hipError_t launch_mixed(int N, const uint8_t* d_stream, long nframes, const cf* d_twN, const float* d_window,
+hipError_t launch_mixed(int N, int variant, const uint8_t* d_stream, long nframes, const cf* d_twN, const float* d_window,
                         double* d_partial, int grid, hipStream_t stream, LaunchInfo* li);
 
 // ---- Bluestein path (KB in rpf_kernels.hip): any other even N <= 4096 ----------

@@ -1,25 +1,34 @@
-// rpf_mixed.hip -- KM: LDS-resident mixed-radix kernel for the "round" sizes people actually
-// type: even N <= 4096 whose prime factors are 2, 3 and 5 and that are not powers of two
-// (500 -- the man page's own example, doc/rtl_power_fftw.1.md:182 --, 1000, 1200, 1500, 2000,
-// 3000, 3600, 4000, ...).  Bluestein (KB) serves such sizes with two power-of-two transforms of
-// 2-4 N points each; a transform of the length itself costs a fifth of that.
+// rpf_mixed.hip -- KM: LDS-resident mixed-radix kernels for the "round" sizes people actually
+// type: even N <= 10000 whose prime factors are 2, 3 and 5 and that are not powers of two
+// (500 -- the man page's own example, doc/rtl_power_fftw.1.md:182 --, 1000, 1200, 2000, 3000,
+// 5000, 10000, ...).  Bluestein (KB) serves such sizes with two power-of-two transforms of 2-4 N
+// points each; a transform of the length itself costs a fifth of that.
 //
-// Stockham autosort, decimation in frequency, one radix per pass (radices 5, 4, 3, 2 in the
-// order the host picks), natural order in and out, two LDS buffers per frame slot:
+// Two kernels:
+//  * mixed_plan_kernel (mixed_core.h, dft_small.h): K1's scheme -- in place by element name
+//    through one padded LDS slab, composite radices up to 25 (two to four passes), twiddles and the
+//    f64 accumulators in registers for the whole launch -- compiled for the sizes of
+//    mixed_plans.inc with the plan (radices, butterflies per thread, frame slots per workgroup,
+//    twiddle placement) that measured fastest on the GPU (tools/gen_mixed_plans.py,
+//    tools/pick_mixed_plans.py, profiles/r02_mixed_plan_search.txt).  500 ... 1060 Gsample/s.
+//  * mixed_kernel: any other such size up to 5120, runtime plan: Stockham autosort, decimation in
+//    frequency, one radix (5, 4, 3, 2) per pass, natural order in and out, two LDS buffers per
+//    frame slot:
 //
 //   pass with sub-length n = N / s, n1 = n / r, butterfly (p < n1, q < s):
 //       y[q + s (r p + j)] = W_n^{p j} * sum_k x[q + s (p + k n1)] W_r^{j k},     W_n^{p j} = W_N^{p j s}
 //
-// The first pass reads the u8 samples straight from HBM (2-byte loads, coalesced across the
-// threads of a frame) and applies (v - 127) (-1)^n [window] exactly like K1; the last pass leaves
-// the spectrum in natural order in LDS, and |X|^2 goes into double accumulators that live in
-// LDS for the whole launch (one owner thread per bin: plain read-modify-write).  TPF threads per
-// frame (a power of two, about N/4), WG / TPF frames side by side in a 256-thread workgroup.
-// HBM traffic = the 2N input bytes per frame; bound by VALU + LDS like K1, less tuned than K1.
+//    The first pass reads the u8 samples straight from HBM (2-byte loads, coalesced across the
+//    threads of a frame) and applies (v - 127) (-1)^n [window] exactly like K1; the last pass
+//    leaves |X|^2 in double accumulators that live in LDS for the whole launch (one owner thread
+//    per bin: plain read-modify-write).  TPF threads per frame (a power of two, about N/4),
+//    WG / TPF frames side by side in a 256-thread workgroup.  100 ... 300 Gsample/s.
+// HBM traffic of both = the 2N input bytes per frame; bound by VALU + LDS like K1.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 
+#include "mixed_core.h"
 #include "rpf_device_common.h"
 #include "rpf_kernels.h"
 
@@ -35,56 +44,6 @@ struct MixedPlan {
     int radix[kMaxFactors];
 };
 
-// r-point DFT of v[0..r) in place (forward, e^{-2 pi i / r}); constants correctly rounded floats.
-template <int R>
-__device__ __forceinline__ void small_dft(cf* v);
-
-template <>
-__device__ __forceinline__ void small_dft<2>(cf* v)
-{
-    const cf a = v[0], b = v[1];
-    v[0] = a + b;
-    v[1] = a - b;
-}
-
-template <>
-__device__ __forceinline__ void small_dft<4>(cf* v)
-{
-    Dft<4>::run(v);
-}
-
-template <>
-__device__ __forceinline__ void small_dft<3>(cf* v)
-{
-    constexpr float kS3 = 0.86602540378443864676f;       // sin(2 pi / 3)
-    const cf s = v[1] + v[2], d = v[1] - v[2];
-    const cf m = v[0] - s * 0.5f;                         // v0 + cos(2 pi/3) (v1 + v2)
-    const cf jd = mul_mi(d) * kS3;                        // -i sin(2 pi/3) (v1 - v2)
-    v[0] = v[0] + s;
-    v[1] = m + jd;
-    v[2] = m - jd;
-}
-
-template <>
-__device__ __forceinline__ void small_dft<5>(cf* v)
-{
-    constexpr float kC1 = 0.30901699437494742410f;       // cos(2 pi / 5)
-    constexpr float kC2 = -0.80901699437494742410f;      // cos(4 pi / 5)
-    constexpr float kS1 = 0.95105651629515357212f;       // sin(2 pi / 5)
-    constexpr float kS2 = 0.58778525229247312917f;       // sin(4 pi / 5)
-    const cf s14 = v[1] + v[4], d14 = v[1] - v[4];
-    const cf s23 = v[2] + v[3], d23 = v[2] - v[3];
-    const cf a1 = v[0] + s14 * kC1 + s23 * kC2;
-    const cf a2 = v[0] + s14 * kC2 + s23 * kC1;
-    const cf b1 = mul_mi(d14 * kS1 + d23 * kS2);          // -i (...)
-    const cf b2 = mul_mi(d14 * kS2 - d23 * kS1);
-    v[0] = v[0] + s14 + s23;
-    v[1] = a1 + b1;
-    v[4] = a1 - b1;
-    v[2] = a2 + b2;
-    v[3] = a2 - b2;
-}
-
 // b / s for 0 <= b < 4096, 1 <= s <= 4096 without an integer division (s is not a power of two)
 __device__ __forceinline__ int div_small(int b, int s, float inv_s)
 {
@@ -97,18 +56,14 @@ __device__ __forceinline__ int div_small(int b, int s, float inv_s)
 // One pass of radix R over one frame: x (LDS, or the raw stream when FIRST) -> y (LDS), or, in
 // the LAST pass, straight into the double accumulators (a butterfly owns the same R bins in every
 // frame, so the spectrum never goes back to LDS).  tw: W_N^k in LDS.
-// CN/CS/CN1/CTPF > 0: N, s, n1 and the threads per frame are compile-time constants (the
-// specialised kernels below): strides fold into DS immediates, b / s into a multiply-shift,
-// and the butterfly loop unrolls -- the generic form spends 3/4 of its instructions on indices.
-template <int R, bool FIRST, bool LAST, int CN = 0, int CS = 0, int CN1 = 0, int CTPF = 0>
+template <int R, bool FIRST, bool LAST>
 __device__ __forceinline__ void mixed_pass(const cf* __restrict__ x, cf* __restrict__ y, const uint8_t* __restrict__ frame,
                                            const float* __restrict__ window, const cf* __restrict__ tw, double* acc,
-                                           bool active, int N_, int s_, int n1_, int t, int tpf_)
+                                           bool active, int N, int s, int n1, int t, int tpf)
 {
-    const int N = CN ? CN : N_, s = CS ? CS : s_, n1 = CN1 ? CN1 : n1_, tpf = CTPF ? CTPF : tpf_;
     const float inv_s = 1.0f / static_cast<float>(s);
-    auto butterfly = [&](int b) {
-        const int p = FIRST ? b : (CS ? b / (CS ? CS : 1) : div_small(b, s, inv_s)), q = FIRST ? 0 : b - p * s;
+    for (int b = t; b < N / R; b += tpf) {
+        const int p = FIRST ? b : div_small(b, s, inv_s), q = FIRST ? 0 : b - p * s;
         cf v[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
@@ -122,7 +77,7 @@ __device__ __forceinline__ void mixed_pass(const cf* __restrict__ x, cf* __restr
                 v[k] = x[q + s * (p + k * n1)];
             }
         }
-        small_dft<R>(v);
+        SmallDft<R>::run(v);
         const int o = q + s * (R * p);
         if constexpr (LAST) {
             // n1 = 1, p = 0: no twiddles; pwr += Re^2 + Im^2 in double (datastore.cxx:83-85)
@@ -143,16 +98,6 @@ __device__ __forceinline__ void mixed_pass(const cf* __restrict__ x, cf* __restr
                 for (int j = 1; j < R; ++j) y[o + s * j] = cmul(v[j], tw[p * j * s]);   // W_n^{p j} = W_N^{p j s}, p j s < N
             }
         }
-    };
-    if constexpr (CN > 0) {
-        constexpr int BFLY = CN / R, ITER = (BFLY + CTPF - 1) / CTPF;
-#pragma unroll
-        for (int i = 0; i < ITER; ++i) {
-            const int b = t + i * CTPF;
-            if ((i + 1) * CTPF <= BFLY || b < BFLY) butterfly(b);
-        }
-    } else {
-        for (int b = t; b < N / R; b += tpf) butterfly(b);
     }
 }
 
@@ -224,97 +169,221 @@ __global__ __launch_bounds__(kMixedWG) void mixed_kernel(const uint8_t* __restri
     }
 }
 
-// ---- specialised kernels: every constant known at compile time --------------------------------
-constexpr int threads_per_frame_c(int N)
+// ---- planned kernels (mixed_core.h): K1's scheme for composite lengths -------------------------
+// In place by element name through one padded slab per frame slot, composite radices up to 25
+// (two or three passes where the Stockham kernels above take four to seven), twiddles and
+// accumulators in registers for the whole launch, the next frame's samples prefetched into
+// registers while the current one is transformed.
+template <class PL, int I>
+__device__ __forceinline__ void plan_load_twiddles(int t, const cf* __restrict__ twN, cf* tw)
 {
-    int tpf = 64;
-    while (tpf < 256 && tpf < N / 4) tpf *= 2;
-    return tpf;
+    if constexpr (I < PL::F - 1) {
+        if (t < PL::TPF(I)) {
+#pragma unroll
+            for (int g = 0; g < PL::G(I); ++g)
+#pragma unroll
+                for (int k = 1; k < PL::R(I); ++k)
+                    tw[PL::tw_offset(I) + g * (PL::R(I) - 1) + k - 1] = twN[mix_twiddle_index<PL, I>(t, g, k)];
+        }
+        plan_load_twiddles<PL, I + 1>(t, twN, tw);
+    }
 }
-
-// the twiddle table sits in LDS unless leaving it in HBM/L1 lets one more workgroup onto the CU
-// (measured: N = 3000 158 -> 240 Gsample/s without it, N = 4000 171 -> 114)
-constexpr bool spec_tw_in_lds(int N)
+// LDS table: pass I's block is [g][k - 1][t], so the threads of a wave read consecutive entries
+template <class PL, int I>
+__device__ __forceinline__ void plan_fill_table(int tid, const cf* __restrict__ twN, cf* table)
 {
-    const int slots = kMixedWG / threads_per_frame_c(N);
-    const int base = slots * N * (2 * (int)sizeof(cf) + (int)sizeof(double));
-    return (160 * 1024) / (base + N * (int)sizeof(cf)) >= (160 * 1024) / base;
-}
-
-template <int N, int TPF, int S, bool FIRST, int R, int... Rest>
-__device__ __forceinline__ void spec_passes(cf* src, cf* dst, const uint8_t* frame, const float* window, const cf* tw,
-                                            double* acc, bool active, int t)
-{
-    constexpr int n1 = N / S / R;
-    constexpr bool last = sizeof...(Rest) == 0;
-    mixed_pass<R, FIRST, last, N, S, n1, TPF>(src, dst, frame, window, tw, acc, active, N, S, n1, t, TPF);
-    if constexpr (!last) {
-        __syncthreads();
-        spec_passes<N, TPF, S * R, false, Rest...>(dst, src, frame, window, tw, acc, active, t);
+    if constexpr (I < PL::F - 1) {
+        constexpr int R = PL::R(I), T = PL::TPF(I), n = PL::G(I) * (R - 1) * T;
+        for (int i = tid; i < n; i += PL::WG) {
+            const int t = i % T, gk = i / T, g = gk / (R - 1), k = gk % (R - 1) + 1;
+            table[PL::tw_table_offset(I) + i] = twN[mix_twiddle_index<PL, I>(t, g, k)];
+        }
+        plan_fill_table<PL, I + 1>(tid, twN, table);
     }
 }
 
-template <int N, int... Rs>
-__global__ __launch_bounds__(kMixedWG) void mixed_spec_kernel(const uint8_t* __restrict__ stream, long nframes,
-                                                             const cf* __restrict__ twN, const float* __restrict__ window,
-                                                             double* __restrict__ partial)
+template <class PL, int I>
+__device__ __forceinline__ void plan_later_passes(int t, cf* slab, const cf* tw, const cf* table, double* acc, bool active)
 {
-    constexpr int TPF = threads_per_frame_c(N), FPW = kMixedWG / TPF;
+    if constexpr (I < PL::F) {
+        constexpr int R = PL::R(I);
+        constexpr bool last = I == PL::F - 1;
+        if (PL::TPF(I) == PL::TPFMAX || t < PL::TPF(I)) {
+#pragma unroll
+            for (int g = 0; g < PL::G(I); ++g) {
+                const int sb = mix_slot_base<PL, I>(t, g);
+                cf v[R];
+                mix_fetch<PL, I>(sb, v, slab);
+                if constexpr (last) {
+                    mix_butterfly<PL, I>(v, nullptr);
+                    if (active) phase_accumulate(v, acc + g * R, R);
+                } else {
+                    if constexpr (PL::TW == 0) {
+                        mix_butterfly<PL, I>(v, tw + PL::tw_offset(I) + g * (R - 1));
+                    } else {
+                        cf twj[R - 1];
+#pragma unroll
+                        for (int k = 0; k < R - 1; ++k)
+                            twj[k] = table[PL::tw_table_offset(I) + (g * (R - 1) + k) * PL::TPF(I) + t];
+                        mix_butterfly<PL, I>(v, twj);
+                    }
+                    mix_store<PL, I>(sb, v, slab);
+                }
+            }
+        }
+        exchange_sync<true>();       // after the last pass: the next frame's pass 0 overwrites the slab
+        plan_later_passes<PL, I + 1>(t, slab, tw, table, acc, active);
+    }
+}
+
+// pass 0 of butterflies G, G+1, ... of a thread: unpack from the raw registers, transform, store
+template <class PL, bool WINDOW, int G>
+__device__ __forceinline__ void plan_first_pass(int t, cf* slab, const cf* tw, const cf* table, const uint32_t* raw,
+                                                const float* sgn, const float* wsgn)
+{
+    if constexpr (G < PL::G(0)) {
+        constexpr int R0 = PL::R(0), T0 = PL::TPF(0);
+        cf v[R0];
+        if constexpr (WINDOW && PL::WLDS) mix_unpack<PL, WINDOW, G * R0, PL::S(0)>(raw, sgn[G], wsgn + G * T0, v);
+        else mix_unpack<PL, WINDOW, G * R0>(raw, sgn[G], wsgn + (WINDOW ? G * R0 : 0), v);
+        if constexpr (PL::TW == 0) {
+            mix_butterfly<PL, 0>(v, tw + G * (R0 - 1));
+        } else {
+            cf twj[R0 - 1];
+#pragma unroll
+            for (int k = 0; k < R0 - 1; ++k) twj[k] = table[(G * (R0 - 1) + k) * T0 + t];
+            mix_butterfly<PL, 0>(v, twj);
+        }
+        mix_store<PL, 0>(mix_slot_base<PL, 0>(t, G), v, slab);
+        plan_first_pass<PL, WINDOW, G + 1>(t, slab, tw, table, raw, sgn, wsgn);
+    }
+}
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+template <class PL, bool WINDOW>
+__global__ __launch_bounds__(PL::WG) void mixed_plan_kernel(const uint8_t* __restrict__ stream, long nframes,
+                                                           const cf* __restrict__ twN, const float* __restrict__ window,
+                                                           double* __restrict__ partial)
+{
+    constexpr int N = PL::N, R0 = PL::R(0), G0 = PL::G(0), T0 = PL::TPF(0), S0 = PL::S(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
-    const int fs = tid / TPF, t = tid % TPF;
-    cf* const bufA = reinterpret_cast<cf*>(smem) + fs * 2 * N;
-    cf* const bufB = bufA + N;
-    double* const acc_all = reinterpret_cast<double*>(smem + FPW * 2 * N * sizeof(cf));
-    double* const acc = acc_all + fs * N;
-    constexpr bool TWLDS = spec_tw_in_lds(N);
-    cf* const twl = reinterpret_cast<cf*>(acc_all + FPW * N);
-    const cf* const tw = TWLDS ? twl : twN;
-    for (int bin = t; bin < N; bin += TPF) acc[bin] = 0.0;
-    if constexpr (TWLDS)
-        for (int k = tid; k < N; k += kMixedWG) twl[k] = twN[k];
+    const int fs = tid / PL::TPFMAX, t = tid - fs * PL::TPFMAX;
+    cf* const slab = reinterpret_cast<cf*>(smem) + fs * PL::LDS_CPX;
+    cf* const table = reinterpret_cast<cf*>(smem) + PL::FPW * PL::LDS_CPX;
+    const bool in0 = T0 == PL::TPFMAX || t < T0;
+
+    cf tw[PL::TW == 0 ? (PL::NTW > 0 ? PL::NTW : 1) : 1];
+    if constexpr (PL::TW == 0) plan_load_twiddles<PL, 0>(t, twN, tw);
+    else plan_fill_table<PL, 0>(tid, twN, table);
+
+    float sgn[G0];
+    float wsgn[WINDOW && !PL::WLDS ? PL::PPT0 : 1];
+    float* const wlds = reinterpret_cast<float*>(table + (PL::TW == 1 ? PL::TW_TABLE : 0));   // window[n] (-1)^n
+#pragma unroll
+    for (int g = 0; g < G0; ++g) sgn[g] = ((t + g * T0) & 1) ? -1.0f : 1.0f;
+    if constexpr (WINDOW && PL::WLDS) {
+        for (int n = tid; n < N; n += PL::WG) wlds[n] = window[n] * ((n & 1) ? -1.0f : 1.0f);       // datastore.cxx:73,76-77
+    } else if constexpr (WINDOW) {
+#pragma unroll
+        for (int g = 0; g < G0; ++g)
+#pragma unroll
+            for (int n1 = 0; n1 < R0; ++n1) {
+                const int n = mix_sample_index<PL>(t, g, n1);
+                wsgn[g * R0 + n1] = in0 ? window[n] * ((n & 1) ? -1.0f : 1.0f) : 0.0f;   // datastore.cxx:73,76-77
+            }
+    }
+    double acc[PL::PPTL];
+#pragma unroll
+    for (int a = 0; a < PL::PPTL; ++a) acc[a] = 0.0;
+
+    // the thread's samples of a frame: n = t + g T0 + n1 S0 (2-byte loads, consecutive across the wave),
+    // two to a register (d16 / d16_hi loads)
+    uint32_t raw[PL::NRAW];
+    auto load_raw = [&](long frame) {
+        const uint8_t* const p = stream + (frame < nframes ? frame : nframes - 1) * (2L * N) + 2 * t;
+#pragma unroll
+        for (int j = 0; j < PL::NRAW; ++j) {
+            const int i0 = 2 * j, i1 = 2 * j + 1;
+            us2 v;
+            v.x = *reinterpret_cast<const uint16_t*>(p + 2 * ((i0 / R0) * T0 + (i0 % R0) * S0));
+            v.y = i1 < PL::PPT0 ? *reinterpret_cast<const uint16_t*>(p + 2 * ((i1 / R0) * T0 + (i1 % R0) * S0)) : 0;
+            raw[j] = __builtin_bit_cast(uint32_t, v);
+        }
+    };
+    const long stride = static_cast<long>(gridDim.x) * PL::FPW;
+    long fb = static_cast<long>(blockIdx.x) * PL::FPW;
+    if (in0) load_raw(fb + fs);
     __syncthreads();
-    const long stride = static_cast<long>(gridDim.x) * FPW;
 #pragma unroll 1
-    for (long fb = static_cast<long>(blockIdx.x) * FPW; fb < nframes; fb += stride) {
+    for (; fb < nframes; fb += stride) {
         const bool active = (fb + fs) < nframes;
-        const uint8_t* const frame = stream + (active ? fb + fs : nframes - 1) * (2L * N);
-        spec_passes<N, TPF, 1, true, Rs...>(bufB, bufA, frame, window, tw, acc, active, t);
-        __syncthreads();
+        if (in0) {
+            plan_first_pass<PL, WINDOW, 0>(t, slab, tw, table, raw, sgn, WINDOW && PL::WLDS ? wlds + t : wsgn);
+            load_raw(fb + stride + fs);          // lands while the later passes run
+        }
+        exchange_sync<true>();
+        plan_later_passes<PL, 1>(t, slab, tw, table, acc, active);
     }
     __syncthreads();
-    for (int bin = tid; bin < N; bin += kMixedWG) {
+    // the slots' partial spectra through LDS into natural bin order, summed in slot order
+    double* const stage = reinterpret_cast<double*>(smem);
+    if (PL::TPF(PL::F - 1) == PL::TPFMAX || t < PL::TPF(PL::F - 1)) {
+#pragma unroll
+        for (int g = 0; g < PL::G(PL::F - 1); ++g)
+#pragma unroll
+            for (int k = 0; k < PL::RLAST; ++k) stage[fs * N + mix_bin<PL>(t, g, k)] = acc[g * PL::RLAST + k];
+    }
+    __syncthreads();
+    for (int bin = tid; bin < N; bin += PL::WG) {
         double v = 0.0;
 #pragma unroll
-        for (int k = 0; k < FPW; ++k) v += acc_all[k * N + bin];
+        for (int k = 0; k < PL::FPW; ++k) v += stage[k * N + bin];
         partial[static_cast<size_t>(blockIdx.x) * N + bin] = v;
     }
 }
 
-using SpecFn = void (*)(const uint8_t*, long, const cf*, const float*, double*);
-struct SpecEntry {
-    int N;
-    SpecFn fn;
+using PlanFn = void (*)(const uint8_t*, long, const cf*, const float*, double*);
+struct PlanEntry {
+    int N, variant;
+    PlanFn plain, windowed;
+    int wg, fpw, lds, lds_windowed;
 };
-// The sizes people type; any other 5-smooth size runs on the generic kernel above.
-const SpecEntry kSpec[] = {
-    {100, mixed_spec_kernel<100, 5, 5, 4>},       {200, mixed_spec_kernel<200, 5, 5, 4, 2>},
-    {250, mixed_spec_kernel<250, 5, 5, 5, 2>},    {300, mixed_spec_kernel<300, 5, 5, 4, 3>},
-    {400, mixed_spec_kernel<400, 5, 5, 4, 4>},    {500, mixed_spec_kernel<500, 5, 5, 5, 4>},
-    {600, mixed_spec_kernel<600, 5, 5, 4, 3, 2>}, {800, mixed_spec_kernel<800, 5, 5, 4, 4, 2>},
-    {1000, mixed_spec_kernel<1000, 5, 5, 5, 4, 2>},    {1200, mixed_spec_kernel<1200, 5, 5, 4, 4, 3>},
-    {1500, mixed_spec_kernel<1500, 5, 5, 5, 4, 3>},    {1600, mixed_spec_kernel<1600, 5, 5, 4, 4, 4>},
-    {2000, mixed_spec_kernel<2000, 5, 5, 5, 4, 4>},    {2400, mixed_spec_kernel<2400, 5, 5, 4, 4, 3, 2>},
-    {2500, mixed_spec_kernel<2500, 5, 5, 5, 5, 4>},    {3000, mixed_spec_kernel<3000, 5, 5, 5, 4, 3, 2>},
-    {3200, mixed_spec_kernel<3200, 5, 5, 4, 4, 4, 2>}, {3600, mixed_spec_kernel<3600, 5, 5, 4, 4, 3, 3>},
-    {4000, mixed_spec_kernel<4000, 5, 5, 5, 4, 4, 2>}, {4800, mixed_spec_kernel<4800, 5, 5, 4, 4, 4, 3>},
-    {5000, mixed_spec_kernel<5000, 5, 5, 5, 5, 4, 2>}, {6000, mixed_spec_kernel<6000, 5, 5, 5, 4, 4, 3>},
-    {6400, mixed_spec_kernel<6400, 5, 5, 4, 4, 4, 4>},
-};
-const SpecEntry* find_spec(int N)
+template <class PL>
+constexpr int plan_lds_bytes(bool windowed)
 {
-    for (const SpecEntry& e : kSpec)
-        if (e.N == N) return &e;
+    return (PL::FPW * PL::LDS_CPX + (PL::TW == 1 ? PL::TW_TABLE : 0)) * (int)sizeof(cf) +
+           (windowed && PL::WLDS ? PL::N * (int)sizeof(float) : 0);
+}
+template <class PL>
+constexpr PlanEntry plan_entry(int variant)
+{
+    return {PL::N, variant, mixed_plan_kernel<PL, false>, mixed_plan_kernel<PL, true>, PL::WG, PL::FPW,
+            plan_lds_bytes<PL>(false), plan_lds_bytes<PL>(true)};
+}
+template <int R, int G = 1>
+using P = MPass<R, G>;
+// variant 0 of a size is what ships (mixed_plans.inc, picked from GPU timings of the candidates by
+// tools/pick_mixed_plans.py); the candidates themselves (tools/gen_mixed_plans.py) exist in the
+// tuning build only, without their windowed twins.
+#ifdef RPF_TUNING
+template <class PL>
+constexpr PlanEntry plan_candidate(int variant)
+{
+    return {PL::N, variant, mixed_plan_kernel<PL, false>, nullptr, PL::WG, PL::FPW, plan_lds_bytes<PL>(false), 0};
+}
+#endif
+const PlanEntry kPlans[] = {
+#include "mixed_plans.inc"
+#ifdef RPF_TUNING
+#include "mixed_plans_tuning.inc"
+#endif
+};
+const PlanEntry* find_plan(int N, int variant)
+{
+    for (const PlanEntry& e : kPlans)
+        if (e.N == N && e.variant == variant) return &e;
     return nullptr;
 }
 
@@ -339,61 +408,83 @@ int threads_per_frame(int N)
     return tpf;
 }
 
-int lds_bytes(int N)       // [frame slots][2 buffers + accumulators] (+ the twiddle table)
+int lds_bytes(int N)       // [frame slots][2 buffers + accumulators] + the twiddle table
 {
-    const bool table = !find_spec(N) || spec_tw_in_lds(N);
-    return (kMixedWG / threads_per_frame(N)) * N * (2 * (int)sizeof(cf) + (int)sizeof(double)) +
-           (table ? N * (int)sizeof(cf) : 0);
+    return (kMixedWG / threads_per_frame(N)) * N * (2 * (int)sizeof(cf) + (int)sizeof(double)) + N * (int)sizeof(cf);
 }
 
 }  // namespace
 
-// even N whose frame (two buffers + accumulators [+ twiddles]) fits one workgroup's LDS -- up to 5120
-// bins for any such size, 6400 for the specialised ones --, only prime factors 2, 3, 5, not a power
-// of two (those are K1's)
-bool mixed_supported(int N)
+// even N whose frame fits one workgroup's LDS, only prime factors 2, 3, 5, not a power of two (those
+// are K1's): a planned kernel for the sizes in kPlans (up to 10000 bins), the Stockham kernel for the
+// rest (up to 5120 bins).  variant != 0 (tuning build): another plan of the same size; 100 = the
+// Stockham kernel for a size that has a plan.
+#ifdef RPF_TUNING
+constexpr int kStockhamVariant = 100;
+#endif
+bool mixed_supported(int N, int variant)
 {
-    if (N < 2 || (N & 1) || N > 6400 || (N & (N - 1)) == 0) return false;
+    if (N < 2 || (N & 1)) return false;
+#ifdef RPF_TUNING
+    if (variant != 0 && find_plan(N, variant)) return true;      // (candidates for K1's sizes can be timed, too)
+#endif
+    if ((N & (N - 1)) == 0) return false;
+    if (find_plan(N, variant)) return true;
+#ifndef RPF_TUNING
+    if (variant != 0) return false;
+#else
+    if (variant != 0 && variant != kStockhamVariant) return false;
+#endif
     MixedPlan plan;
     return factorise(N, &plan) && lds_bytes(N) <= 160 * 1024;
 }
 
-hipError_t plan_mixed(int N, int device, LaunchInfo* li)
+hipError_t plan_mixed(int N, int variant, bool windowed, int device, LaunchInfo* li)
 {
-    if (!mixed_supported(N)) return hipErrorInvalidValue;
-    const int lds = lds_bytes(N);
-    const SpecEntry* spec = find_spec(N);
-    const void* fn = spec ? reinterpret_cast<const void*>(spec->fn) : reinterpret_cast<const void*>(mixed_kernel);
+    if (!mixed_supported(N, variant)) return hipErrorInvalidValue;
+    const PlanEntry* pe = find_plan(N, variant);
+    if (pe && windowed && !pe->windowed) return hipErrorInvalidValue;      // (a tuning-build candidate)
+    const int lds = pe ? (windowed ? pe->lds_windowed : pe->lds) : lds_bytes(N);
+    const int wg = pe ? pe->wg : kMixedWG;
+    const void* fn = pe ? reinterpret_cast<const void*>(windowed ? pe->windowed : pe->plain)
+                        : reinterpret_cast<const void*>(mixed_kernel);
     hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (err != hipSuccess) return err;
     int per_cu = 0;
-    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kMixedWG, lds);
+    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, wg, lds);
     if (err != hipSuccess) return err;
     hipDeviceProp_t prop;
     if ((err = hipGetDeviceProperties(&prop, device)) != hipSuccess) return err;
     li->grid = std::max(per_cu, 1) * prop.multiProcessorCount;
-    li->block = kMixedWG;
-    li->fpw = kMixedWG / threads_per_frame(N);
+    li->block = wg;
+    li->fpw = pe ? pe->fpw : kMixedWG / threads_per_frame(N);
     li->lds_bytes = lds;
     return hipSuccess;
 }
 
 // d_twN: master twiddles W_N^k (make_twiddles); one partial spectrum of N doubles per workgroup.
-hipError_t launch_mixed(int N, const uint8_t* d_stream, long nframes, const cf* d_twN, const float* d_window,
+hipError_t launch_mixed(int N, int variant, const uint8_t* d_stream, long nframes, const cf* d_twN, const float* d_window,
                         double* d_partial, int grid, hipStream_t stream, LaunchInfo* li)
 {
-    MixedPlan plan;
-    if (!mixed_supported(N) || !factorise(N, &plan) || grid < 1) return hipErrorInvalidValue;
-    const int tpf = threads_per_frame(N), lds = lds_bytes(N);
-    if (const SpecEntry* spec = find_spec(N))
-        hipLaunchKernelGGL(spec->fn, dim3(grid), dim3(kMixedWG), lds, stream, d_stream, nframes, d_twN, d_window, d_partial);
-    else
-        hipLaunchKernelGGL(mixed_kernel, dim3(grid), dim3(kMixedWG), lds, stream, d_stream, nframes, N, tpf, plan, d_twN,
+    if (!mixed_supported(N, variant) || grid < 1) return hipErrorInvalidValue;
+    int wg = kMixedWG, fpw = 0, lds = 0;
+    if (const PlanEntry* pe = find_plan(N, variant)) {
+        wg = pe->wg, fpw = pe->fpw, lds = d_window ? pe->lds_windowed : pe->lds;
+        if (d_window && !pe->windowed) return hipErrorInvalidValue;      // (a tuning-build candidate)
+        hipLaunchKernelGGL(d_window ? pe->windowed : pe->plain, dim3(grid), dim3(wg), lds, stream, d_stream, nframes, d_twN,
                            d_window, d_partial);
+    } else {
+        MixedPlan plan;
+        if (!factorise(N, &plan)) return hipErrorInvalidValue;
+        const int tpf = threads_per_frame(N);
+        fpw = kMixedWG / tpf, lds = lds_bytes(N);
+        hipLaunchKernelGGL(mixed_kernel, dim3(grid), dim3(kMixedWG), lds, stream, d_stream, nframes, N, tpf, plan, d_twN,
+                               d_window, d_partial);
+    }
     if (li) {
         li->grid = grid;
-        li->block = kMixedWG;
-        li->fpw = kMixedWG / tpf;
+        li->block = wg;
+        li->fpw = fpw;
         li->lds_bytes = lds;
     }
     return hipGetLastError();

@@ -13,6 +13,7 @@
 
 #include "../../rtl-power-fftw_amd/csrc/bluestein_tables.h"
 #include "../../rtl-power-fftw_amd/csrc/fft_core.h"
+#include "../../rtl-power-fftw_amd/csrc/mixed_core.h"
 
 namespace {
 
@@ -158,7 +159,116 @@ int run_bluestein(int N, const float* window, const uint8_t* stream, long nframe
     return 0;
 }
 
+// KM (mixed_plan_kernel in rpf_mixed.hip): the same per-thread functions (mixed_core.h), one
+// "thread" after the other, a barrier between passes.
+template <class PL, int I>
+void mixed_passes(std::vector<std::vector<cf>>& tws, std::vector<cf>& slab, const uint8_t* frame,
+                  const float* window, std::vector<std::vector<double>>& acc)
+{
+    if constexpr (I < PL::F) {
+        constexpr int R = PL::R(I), G = PL::G(I);
+        for (int t = 0; t < PL::TPF(I); ++t)
+            for (int g = 0; g < G; ++g) {
+                cf v[R];
+                if constexpr (I == 0) {
+                    uint32_t raw[(R + 1) / 2] = {};
+                    float wsgn[R];
+                    for (int n1 = 0; n1 < R; ++n1) {
+                        const int n = rpf::mix_sample_index<PL>(t, g, n1);
+                        raw[n1 >> 1] |= (frame[2 * n] | (uint32_t)frame[2 * n + 1] << 8) << (16 * (n1 & 1));
+                        wsgn[n1] = window ? window[n] * ((n & 1) ? -1.0f : 1.0f) : 0.0f;
+                    }
+                    const float sgn = ((t + g * PL::TPF(0)) & 1) ? -1.0f : 1.0f;
+                    if (window) rpf::mix_unpack<PL, true, 0>(raw, sgn, wsgn, v);
+                    else rpf::mix_unpack<PL, false, 0>(raw, sgn, wsgn, v);
+                } else {
+                    rpf::mix_fetch<PL, I>(rpf::mix_slot_base<PL, I>(t, g), v, slab.data());
+                }
+                rpf::mix_butterfly<PL, I>(v, tws[t].data() + PL::tw_offset(I) + g * (R - 1));
+                if constexpr (I < PL::F - 1) {
+                    rpf::mix_store<PL, I>(rpf::mix_slot_base<PL, I>(t, g), v, slab.data());
+                } else {
+                    rpf::phase_accumulate(v, acc[t].data() + g * R, R);
+                }
+            }
+        mixed_passes<PL, I + 1>(tws, slab, frame, window, acc);
+    }
+}
+template <class PL, int I>
+void mixed_load_tw(int t, const std::vector<cf>& twN, cf* tw)
+{
+    if constexpr (I < PL::F - 1) {
+        if (t < PL::TPF(I))
+            for (int g = 0; g < PL::G(I); ++g)
+                for (int k = 1; k < PL::R(I); ++k)
+                    tw[PL::tw_offset(I) + g * (PL::R(I) - 1) + k - 1] = twN[rpf::mix_twiddle_index<PL, I>(t, g, k)];
+        mixed_load_tw<PL, I + 1>(t, twN, tw);
+    }
+}
+template <class PL>
+int run_mixed(const float* window, const uint8_t* stream, long nframes, double* pwr)
+{
+    constexpr int N = PL::N;
+    std::vector<cf> twN(N);
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (int k = 0; k < N; ++k) {
+        long double a = two_pi * k / N;
+        twN[k] = {(float)cosl(a), (float)(-sinl(a))};
+    }
+    std::vector<std::vector<cf>> tws(PL::TPFMAX, std::vector<cf>(PL::NTW + 1));
+    for (int t = 0; t < PL::TPFMAX; ++t) mixed_load_tw<PL, 0>(t, twN, tws[t].data());
+    std::vector<std::vector<double>> acc(PL::TPFMAX, std::vector<double>(PL::PPTL, 0.0));
+    std::vector<cf> slab(PL::LDS_CPX);
+    for (long f = 0; f < nframes; ++f)
+        mixed_passes<PL, 0>(tws, slab, stream + (size_t)f * 2 * N, window, acc);
+    std::vector<int> seen(N, 0);
+    for (int t = 0; t < PL::TPF(PL::F - 1); ++t)
+        for (int g = 0; g < PL::G(PL::F - 1); ++g)
+            for (int k = 0; k < PL::RLAST; ++k) {
+                const int bin = rpf::mix_bin<PL>(t, g, k);
+                if (bin < 0 || bin >= N || seen[bin]++) return -2;
+                pwr[bin] = acc[t][g * PL::RLAST + k];
+            }
+    return 0;
+}
+
 }  // namespace
+
+using rpf::MixPlan;
+using rpf::MPass;
+extern "C" int rpf_emul_mixed(int plan, const float* window, const uint8_t* stream, long nframes, double* pwr)
+{
+    switch (plan) {
+        case 0: return run_mixed<MixPlan<100, 1, 0, MPass<10>, MPass<10>>>(window, stream, nframes, pwr);
+        case 1: return run_mixed<MixPlan<500, 1, 0, MPass<10>, MPass<10>, MPass<5, 2>>>(window, stream, nframes, pwr);
+        case 2: return run_mixed<MixPlan<500, 1, 0, MPass<25>, MPass<20>>>(window, stream, nframes, pwr);
+        case 3: return run_mixed<MixPlan<1000, 1, 0, MPass<10>, MPass<10>, MPass<10>>>(window, stream, nframes, pwr);
+        case 4: return run_mixed<MixPlan<1200, 1, 0, MPass<10>, MPass<12>, MPass<10>>>(window, stream, nframes, pwr);
+        case 5: return run_mixed<MixPlan<300, 1, 0, MPass<5, 2>, MPass<6, 2>, MPass<10>>>(window, stream, nframes, pwr);
+        case 6: return run_mixed<MixPlan<3600, 1, 0, MPass<15>, MPass<16>, MPass<15>>>(window, stream, nframes, pwr);
+        case 7: return run_mixed<MixPlan<1080, 1, 0, MPass<9>, MPass<8>, MPass<15>>>(window, stream, nframes, pwr);
+        case 8: return run_mixed<MixPlan<6000, 1, 0, MPass<20>, MPass<20>, MPass<15>>>(window, stream, nframes, pwr);
+        case 9: return run_mixed<MixPlan<96, 1, 0, MPass<2, 3>, MPass<3, 2>, MPass<4>, MPass<4>>>(window, stream, nframes, pwr);
+    }
+    return -1;
+}
+extern "C" int rpf_emul_mixed_n(int plan)
+{
+    const int n[] = {100, 500, 500, 1000, 1200, 300, 3600, 1080, 6000, 96};
+    return plan >= 0 && plan < 10 ? n[plan] : -1;
+}
+
+// v[k] <- sum_n v[n] W_R^{nk} through dft_small.h (interleaved re, im)
+extern "C" int rpf_emul_small_dft(int R, float* v)
+{
+    cf* c = reinterpret_cast<cf*>(v);
+    switch (R) {
+#define CASE(r) case r: rpf::SmallDft<r>::run(c); return 0
+        CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(8); CASE(9); CASE(10); CASE(12); CASE(15); CASE(16); CASE(18); CASE(20); CASE(24); CASE(25);
+#undef CASE
+    }
+    return -1;
+}
 
 extern "C" int rpf_emul_accumulate(int N, int P, const float* window, const uint8_t* stream,
                                    long nframes, double* pwr)

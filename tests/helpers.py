@@ -67,8 +67,37 @@ def emul_lib():
         lib = ctypes.CDLL(os.path.join(ROOT, "tests", "emul", "librpf_emul.so"))
         lib.rpf_emul_accumulate.argtypes = [ctypes.c_int, ctypes.c_int, fp, u8p, ctypes.c_long, dp]
         lib.rpf_emul_bluestein.argtypes = [ctypes.c_int, fp, u8p, ctypes.c_long, dp]
+        lib.rpf_emul_mixed.argtypes = [ctypes.c_int, fp, u8p, ctypes.c_long, dp]
+        lib.rpf_emul_small_dft.argtypes = [ctypes.c_int, fp]
         _emul = lib
     return _emul
+
+
+def emul_mixed(plan, stream, repeats, window=None):
+    """Plan `plan` of tests/emul's list run through mixed_core.h thread by thread; returns (N, pwr)."""
+    lib = emul_lib()
+    N = lib.rpf_emul_mixed_n(plan)
+    assert N > 0
+    stream = np.ascontiguousarray(stream, dtype=np.uint8)
+    w = None
+    if window is not None:
+        window = np.ascontiguousarray(window, dtype=np.float32)
+        w = window.ctypes.data_as(fp)
+    pwr = np.zeros(N)
+    assert lib.rpf_emul_mixed(plan, w, stream.ctypes.data_as(u8p), repeats, pwr.ctypes.data_as(dp)) == 0
+    return pwr
+
+
+def emul_mixed_n(plan):
+    return emul_lib().rpf_emul_mixed_n(plan)
+
+
+def emul_small_dft(x):
+    """dft_small.h's in-register DFT of len(x) points."""
+    v = np.empty(2 * len(x), np.float32)
+    v[0::2], v[1::2] = x.real, x.imag
+    assert emul_lib().rpf_emul_small_dft(len(x), v.ctypes.data_as(fp)) == 0
+    return v[0::2] + 1j * v[1::2]
 
 
 def oracle_accumulate(N, stream, repeats, window=None, precision=32):

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 import rtl_power_fftw_amd as rpf
-from helpers import emul_accumulate, emul_bluestein, max_err_over_mean, max_rel, oracle_accumulate, truth_f64
+from helpers import (emul_accumulate, emul_bluestein, emul_mixed, emul_mixed_n, emul_small_dft, max_err_over_mean, max_rel,
+                     oracle_accumulate, truth_f64)
 
 CASES = [(64, 8), (128, 8), (256, 8), (512, 8), (1024, 8), (4096, 8), (128, 16), (256, 16), (512, 16),
          (1024, 16), (2048, 16), (4096, 16), (8192, 16)]
@@ -50,3 +51,49 @@ def test_emulated_bluestein_kernel_matches_oracle(N, windowed):
     assert max_rel(got, truth_f64(N, stream, R, w)) < 1e-6
     o32, _ = oracle_accumulate(N, stream, R, w, 32)
     assert max_rel(got, o32) < 1e-6
+
+
+@pytest.mark.parametrize("R", [2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 18, 20, 24, 25])
+def test_small_dft_radices(R):
+    """dft_small.h: the in-register DFTs the mixed-radix kernel uses as radices (prime-factor maps,
+    Cooley-Tukey steps with constexpr twiddles) against numpy's double DFT, and one basis vector per
+    output to pin the index maps."""
+    rng = np.random.default_rng(R)
+    x = (rng.normal(size=R) + 1j * rng.normal(size=R)).astype(np.complex64)
+    ref = np.fft.fft(x.astype(np.complex128))
+    assert np.abs(emul_small_dft(x) - ref).max() < 3e-7 * np.abs(ref).max()
+    for k in range(R):
+        tone = np.exp(2j * np.pi * k * np.arange(R) / R).astype(np.complex64)
+        got = emul_small_dft(tone)
+        assert int(np.argmax(np.abs(got))) == k and abs(got[k] - R) < 1e-5 * R
+        assert np.abs(np.delete(got, k)).max() < 2e-6 * R
+
+
+@pytest.mark.parametrize("plan", range(10))
+@pytest.mark.parametrize("windowed", [False, True])
+def test_emulated_mixed_plan_matches_oracle(plan, windowed):
+    """mixed_core.h (the planned mixed-radix kernel's per-thread code: element names, padded slots,
+    twiddle indices, packed raw samples, bin placement) for two-, three- and four-pass plans with
+    one or several butterflies per thread."""
+    N = emul_mixed_n(plan)
+    R = 12
+    stream = rpf.synth.uniform_iq(70 + plan, N * R)
+    w = rpf.synth.hann_window(N) + np.float32(0.25) if windowed else None
+    got = emul_mixed(plan, stream, R, w)
+    assert max_rel(got, truth_f64(N, stream, R, w)) < 1e-6
+    o32, _ = oracle_accumulate(N, stream, R, w, 32)
+    assert max_rel(got, o32) < 1e-6
+
+
+def test_emulated_mixed_plan_bin_placement():
+    plan = 4                      # 1200 = 10 x 12 x 10
+    N = emul_mixed_n(plan)
+    k0 = 437
+    n = np.arange(N)
+    tone = 50.0 * np.exp(2j * np.pi * k0 * n / N)
+    frame = np.empty(2 * N, dtype=np.uint8)
+    frame[0::2] = np.rint(127 + tone.real)
+    frame[1::2] = np.rint(127 + tone.imag)
+    got = emul_mixed(plan, frame, 1)
+    assert int(np.argmax(got)) == (k0 + N // 2) % N
+    assert np.sort(got)[-2] < 1e-3 * got.max()

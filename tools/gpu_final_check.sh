@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round-end verification on the GPU box: the -m gpu suite, smoke(), the driver's bench command,
+# a rocprofv3 kernel-trace of the mixed-radix sizes, then the randomised stress for the rest of the budget.
+set -u
+ROOT=$GRAFT_REPO_ROOT
+OUT=$ROOT/gpurun_out/final
+mkdir -p $OUT
+cd $ROOT
+timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
+timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/bench_20.json 2> $OUT/bench_20.err; echo "bench rc=$?"; cut -c1-400 $OUT/bench_20.json
+cd /tmp && export TMPDIR=/tmp
+SWEEP_NOWIN=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/km_trace -o km -- python $ROOT/tools/gpu_sweep.py 500:0 1000:0 2000:0 5000:0 > $OUT/km_trace.log 2>&1
+cp $(find $OUT/km_trace -name 'km_kernel_stats.csv' | head -1) $OUT/km_kernel_stats.csv 2>/dev/null
+rm -rf $OUT/km_trace
+cd $ROOT
+timeout 200 python tools/gpu_stress.py ${1:-120} 77 > $OUT/stress.txt 2>&1; echo "stress rc=$?"; tail -3 $OUT/stress.txt

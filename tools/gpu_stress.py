@@ -16,14 +16,28 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 dev = torch.device("cuda:0")
 POW2 = [64, 128, 256, 512, 1024, 2048, 4096, 8192]
 FOUR = [16384, 32768, 65536, 131072, 262144]
+
+
+def five_smooth(n):
+    for p in (2, 3, 5):
+        while n % p == 0:
+            n //= p
+    return n == 1
+
+
+SMOOTH = [n for n in range(6, 10001, 2) if n & (n - 1) and five_smooth(n)]
 t0 = time.time()
 ncase = 0
 worst = 0.0
 worst_case = None
 while time.time() - t0 < budget:
-    fam = rng.integers(0, 10)
+    fam = rng.integers(0, 12)
     flags = 0
-    if fam < 2:
+    if fam >= 10:                                         # LDS mixed-radix kernel (5-smooth, not a power of two)
+        N = int(rng.choice(SMOOTH))
+        if rng.integers(0, 6) == 0:
+            flags = rpf._lib.FLAG_NO_MIXED_RADIX          # the same size through Bluestein
+    elif fam < 2:
         N = int(rng.choice(POW2))
     elif fam < 5:
         N = int(rng.choice(FOUR))
