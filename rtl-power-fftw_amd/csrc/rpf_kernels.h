@@ -40,7 +40,8 @@ hipError_t launch_fft_accum(int N, int vid, bool window, bool use_dma, const uin
 hipError_t launch_reduce(const double* d_partial, int nslots, int N, double* d_out,
                          bool accumulate, hipStream_t stream, bool partial_f32 = false, size_t slot_stride = 0);
 
-// ---- mixed-radix path (KM, rpf_mixed.hip): even N <= 5120 (6400 for the specialised sizes) with prime factors 2, 3, 5 only, not a power of two --
+// ---- mixed-radix path (KM, rpf_mixed.hip): even N with prime factors 2, 3, 5 only, not a power of two: the planned
+// kernel for the sizes of mixed_plans.inc (up to 10000), the Stockham kernel for the rest up to 5120 --
 // variant: 0 = the shipped kernel of the size; others (tuning build only) = alternative plans
 bool mixed_supported(int N, int variant = 0);
 hipError_t plan_mixed(int N, int variant, bool windowed, int device, LaunchInfo* li);
