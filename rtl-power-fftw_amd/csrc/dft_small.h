@@ -1,5 +1,5 @@
 // dft_small.h -- in-register DFTs of the small composite lengths the mixed-radix kernel
-// (rpf_mixed.hip) uses as radices: 2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 18, 20, 24, 25.
+// (rpf_mixed.hip) uses as radices: every length from 2 to 25.
 //
 // SmallDft<R>::run(v): v[k] <- sum_n v[n] W_R^{n k}, W_R = e^{-2 pi i / R}, natural order in and
 // out, everything on registers (all indices are compile-time constants after unrolling, so the
@@ -8,6 +8,7 @@
 //     map -- no twiddles between the two stages at all;
 //   * 9 = 3x3, 25 = 5x5: one Cooley-Tukey step with constant twiddles W_R^m (correctly rounded
 //     floats from a constexpr double evaluation);
+//   * the odd primes 7, 11, 13, 17, 19, 23: the symmetric direct form (PrimeDft), and with it 14, 21, 22;
 //   * 2, 4, 8, 16: fft_core.h's butterflies (K1's).
 // Like fft_core.h this is plain C++17 on `cf` so that the host emulator under tests/emul checks
 // every radix against a naive double DFT on a machine without a GPU.
@@ -159,6 +160,53 @@ struct SmallDft<5> {
     }
 };
 
+// Odd prime P by the symmetric direct form: with s_j = x_j + x_{P-j}, d_j = x_j - x_{P-j} (j <= h = (P-1)/2),
+//   X_0 = x_0 + sum_j s_j,   X_k, X_{P-k} = a_k -+ i b_k,   a_k = x_0 + sum_j s_j cos(2 pi jk/P),  b_k = sum_j d_j sin(2 pi jk/P)
+// -- (P-1)^2 / 2 packed multiply-adds with real constants, about 4 instructions per point at P = 7 (like the
+// hand-written 5 above), 7 at P = 13, 12 at P = 23.
+template <int P>
+struct PrimeTable {
+    float c[P], s[P];
+    constexpr PrimeTable() : c(), s()
+    {
+        for (int m = 0; m < P; ++m) {
+            c[m] = static_cast<float>(cos_turn(m, P));
+            s[m] = static_cast<float>(sin_turn(m, P));
+        }
+    }
+};
+template <int P>
+struct PrimeDft {
+    static constexpr PrimeTable<P> tab{};
+    static RPF_HD void run(cf* v)
+    {
+        constexpr int H = (P - 1) / 2;
+        cf s[H], d[H];
+#pragma unroll
+        for (int j = 1; j <= H; ++j) {
+            s[j - 1] = v[j] + v[P - j];
+            d[j - 1] = v[j] - v[P - j];
+        }
+        const cf x0 = v[0];
+        cf sum = x0;
+#pragma unroll
+        for (int j = 0; j < H; ++j) sum = sum + s[j];
+        v[0] = sum;
+#pragma unroll
+        for (int k = 1; k <= H; ++k) {
+            cf a = x0, b = cf{0.0f, 0.0f};
+#pragma unroll
+            for (int j = 1; j <= H; ++j) {
+                a = a + s[j - 1] * tab.c[(j * k) % P];
+                if (j == 1) b = d[0] * tab.s[k % P];
+                else b = b + d[j - 1] * tab.s[(j * k) % P];
+            }
+            v[k] = add_mi(a, b);          // a - i b
+            v[P - k] = sub_mi(a, b);      // a + i b
+        }
+    }
+};
+
 constexpr int mod_inverse(int a, int m)      // a^-1 mod m (a, m coprime, small)
 {
     for (int x = 1; x < m; ++x)
@@ -234,6 +282,42 @@ struct CtDft {
     }
 };
 
+template <>
+struct SmallDft<7> {
+    static RPF_HD void run(cf* v) { PrimeDft<7>::run(v); }
+};
+template <>
+struct SmallDft<11> {
+    static RPF_HD void run(cf* v) { PrimeDft<11>::run(v); }
+};
+template <>
+struct SmallDft<13> {
+    static RPF_HD void run(cf* v) { PrimeDft<13>::run(v); }
+};
+template <>
+struct SmallDft<17> {
+    static RPF_HD void run(cf* v) { PrimeDft<17>::run(v); }
+};
+template <>
+struct SmallDft<19> {
+    static RPF_HD void run(cf* v) { PrimeDft<19>::run(v); }
+};
+template <>
+struct SmallDft<23> {
+    static RPF_HD void run(cf* v) { PrimeDft<23>::run(v); }
+};
+template <>
+struct SmallDft<14> {
+    static RPF_HD void run(cf* v) { PfaDft<14, 2, 7>::run(v); }
+};
+template <>
+struct SmallDft<21> {
+    static RPF_HD void run(cf* v) { PfaDft<21, 3, 7>::run(v); }
+};
+template <>
+struct SmallDft<22> {
+    static RPF_HD void run(cf* v) { PfaDft<22, 2, 11>::run(v); }
+};
 template <>
 struct SmallDft<6> {
     static RPF_HD void run(cf* v) { PfaDft<6, 2, 3>::run(v); }

@@ -1,5 +1,5 @@
 // rpf_mixed.hip -- KM: LDS-resident mixed-radix kernels for the "round" sizes people actually
-// type: even N <= 10000 whose prime factors are 2, 3 and 5 and that are not powers of two
+// type: even N <= 10000 with small prime factors (2, 3, 5; 7 ... 23 for multiples of 100) that are not powers of two
 // (500 -- the man page's own example, doc/rtl_power_fftw.1.md:182 --, 1000, 1200, 2000, 3000,
 // 5000, 10000, ...).  Bluestein (KB) serves such sizes with two power-of-two transforms of 2-4 N
 // points each; a transform of the length itself costs a fifth of that.

@@ -249,13 +249,16 @@ extern "C" int rpf_emul_mixed(int plan, const float* window, const uint8_t* stre
         case 7: return run_mixed<MixPlan<1080, 1, 0, MPass<9>, MPass<8>, MPass<15>>>(window, stream, nframes, pwr);
         case 8: return run_mixed<MixPlan<6000, 1, 0, MPass<20>, MPass<20>, MPass<15>>>(window, stream, nframes, pwr);
         case 9: return run_mixed<MixPlan<96, 1, 0, MPass<2, 3>, MPass<3, 2>, MPass<4>, MPass<4>>>(window, stream, nframes, pwr);
+        case 10: return run_mixed<MixPlan<700, 1, 0, MPass<7, 2>, MPass<10>, MPass<10>>>(window, stream, nframes, pwr);
+        case 11: return run_mixed<MixPlan<2860, 1, 0, MPass<13>, MPass<11>, MPass<20>>>(window, stream, nframes, pwr);
+        case 12: return run_mixed<MixPlan<782, 1, 0, MPass<17>, MPass<23>, MPass<2, 17>>>(window, stream, nframes, pwr);
     }
     return -1;
 }
 extern "C" int rpf_emul_mixed_n(int plan)
 {
-    const int n[] = {100, 500, 500, 1000, 1200, 300, 3600, 1080, 6000, 96};
-    return plan >= 0 && plan < 10 ? n[plan] : -1;
+    const int n[] = {100, 500, 500, 1000, 1200, 300, 3600, 1080, 6000, 96, 700, 2860, 782};
+    return plan >= 0 && plan < 13 ? n[plan] : -1;
 }
 
 // v[k] <- sum_n v[n] W_R^{nk} through dft_small.h (interleaved re, im)
@@ -264,7 +267,8 @@ extern "C" int rpf_emul_small_dft(int R, float* v)
     cf* c = reinterpret_cast<cf*>(v);
     switch (R) {
 #define CASE(r) case r: rpf::SmallDft<r>::run(c); return 0
-        CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(8); CASE(9); CASE(10); CASE(12); CASE(15); CASE(16); CASE(18); CASE(20); CASE(24); CASE(25);
+        CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(7); CASE(8); CASE(9); CASE(10); CASE(11); CASE(12); CASE(13); CASE(14);
+        CASE(15); CASE(16); CASE(17); CASE(18); CASE(19); CASE(20); CASE(21); CASE(22); CASE(23); CASE(24); CASE(25);
 #undef CASE
     }
     return -1;

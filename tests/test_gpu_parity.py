@@ -123,12 +123,12 @@ def test_non_power_of_two_sizes_match_oracle(N, windowed, torch_dev):
     assert max_rel(host, got) < 1e-13
 
 
-@pytest.mark.parametrize("N", [6, 10, 12, 50, 90, 96, 100, 108, 150, 250, 384, 500, 600, 750, 1000, 1200, 1458, 1500, 1536, 2000,
-                               2430, 3000, 3600, 3750, 4000, 4050, 4374, 4500, 5000, 5120, 6000, 6250, 6400, 7500, 8000, 9000,
-                               9216, 9720, 10000])
+@pytest.mark.parametrize("N", [6, 10, 12, 50, 90, 96, 100, 108, 140, 150, 250, 384, 500, 600, 700, 750, 1000, 1100, 1200, 1300,
+                               1458, 1500, 1536, 1700, 1900, 2000, 2300, 2430, 3000, 3600, 3750, 4000, 4050, 4374, 4500, 5000,
+                               5120, 6000, 6250, 6400, 7000, 7500, 7800, 8000, 9000, 9216, 9500, 9720, 9900, 10000])
 def test_mixed_radix_sizes_match_oracle_and_bluestein(N, torch_dev):
-    """Even N <= 10000 with prime factors 2, 3, 5 only (the "round" sizes, the man page's -b 500
-    among them): LDS mixed-radix kernels (rpf_mixed.hip: the planned kernel for the sizes of
+    """Even N <= 10000 with small prime factors (the "round" sizes, the man page's -b 500 among
+    them; 2, 3, 5 and -- for the multiples of 100 -- 7 ... 23): LDS mixed-radix kernels (rpf_mixed.hip: the planned kernel for the sizes of
     mixed_plans.inc -- two-, three- and four-pass plans, twiddles in registers and in LDS, windowed
     and not --, the Stockham kernel for 6, 10, 12, 108, 1458, 4374) against the float32 oracle,
     float64 truth, and the Bluestein kernels they replace for these sizes; device and queue paths."""

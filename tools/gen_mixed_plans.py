@@ -13,10 +13,10 @@ TPF_i = N / (R_i G_i) threads of a frame take part), FPW frame slots per workgro
 import itertools
 import sys
 
-RADICES = [2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 18, 20, 24, 25]
+RADICES = [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25]
 # packed-f32 instructions of one butterfly (counted from dft_small.h)
 COST = {2: 2, 3: 8, 4: 8, 5: 20, 6: 22, 8: 28, 9: 56, 10: 50, 12: 56, 15: 100, 16: 80, 18: 130, 20: 120,
-        24: 148, 25: 232}
+        24: 148, 25: 232, 7: 33, 11: 75, 13: 102, 17: 170, 19: 210, 23: 300, 14: 80, 21: 155, 22: 172}
 # the decimal "round" sizes people type, and the 3- and 5-multiples of powers of two
 SIZES = [100, 120, 150, 160, 200, 240, 250, 300, 320, 360, 400, 450, 480, 500, 600, 640, 720, 750, 800, 900, 960, 1000,
          1200, 1250, 1280, 1440, 1500, 1600, 1800, 1920, 2000, 2160, 2400, 2500, 2560, 2700, 2880, 3000, 3200, 3600, 3750,
@@ -24,7 +24,11 @@ SIZES = [100, 120, 150, 160, 200, 240, 250, 300, 320, 360, 400, 450, 480, 500, 6
          10000, 150, 750, 3750, 6250,
          # the remaining multiples of 10 with prime factors 2, 3, 5, and 3 2^k / 9 2^k
          50, 60, 80, 90, 180, 270, 540, 810, 1080, 1350, 1620, 2250, 2430, 3240, 4050, 4320, 4860, 6480, 6750, 7290, 9720,
-         96, 192, 384, 768, 1536, 3072, 6144, 576, 1152, 2304, 4608, 9216]
+         96, 192, 384, 768, 1536, 3072, 6144, 576, 1152, 2304, 4608, 9216,
+         # multiples of 100 with a prime factor 7 ... 23 (dft_small.h's PrimeDft)
+         140, 350, 700, 1100, 1300, 1400, 1700, 1900, 2100, 2200, 2300, 2600, 2800, 3300, 3400, 3500, 3800, 3900, 4200, 4400,
+         4600, 4900, 5100, 5200, 5500, 5600, 5700, 6300, 6500, 6600, 6800, 6900, 7000, 7600, 7700, 7800, 8400, 8500, 8800,
+         9100, 9200, 9500, 9800, 9900]
 LDS_LIMIT = 160 * 1024
 
 
@@ -44,7 +48,7 @@ def factorisations(n, maxf=4):
     return out
 
 
-def plans_of(n):
+def plans_of(n, ratio=0.74):
     res = []
     for rad in factorisations(n):
         f = len(rad)
@@ -57,7 +61,7 @@ def plans_of(n):
         for gs in itertools.product(*opts):
             tpf = [n // (r * g) for r, g in zip(rad, gs)]
             tmax = max(tpf)
-            if min(tpf) < 0.74 * tmax:
+            if min(tpf) < ratio * tmax:
                 continue
             per = 0.0
             for i, (r, g) in enumerate(zip(rad, gs)):
@@ -83,8 +87,20 @@ def vgprs(rad, gs, tw):
 
 
 def candidates(n, per_size=18):
+    out = _candidates(n, per_size, 0.74) or _candidates(n, per_size, 0.66) or _candidates(n, per_size, 0.5)
+    for rad, gs, fpw, tw in EXTRA.get(n, []):
+        prod = 1
+        for r, g in zip(rad, gs):
+            prod *= r
+            assert n % (r * g) == 0, (n, rad, gs)
+        assert prod == n and fpw * max(n // (r * g) for r, g in zip(rad, gs)) <= 1024, (n, rad, gs, fpw)
+        out.append((0.0, rad, gs, fpw, tw))
+    return out
+
+
+def _candidates(n, per_size, ratio):
     out = []
-    plans = plans_of(n)
+    plans = plans_of(n, ratio)
     for lo, hi, nshapes in ((0, 12, 2), (13, 16, 1), (17, 25, 2)):       # points per thread: light / middle / heavy
         seen_shapes = set()
         for cost, rad, gs, tpf, tmax in plans:
@@ -124,15 +140,7 @@ def candidates(n, per_size=18):
                 seen_shapes.add(shape)
             if len(seen_shapes) >= nshapes:
                 break
-    out = out[:per_size]
-    for rad, gs, fpw, tw in EXTRA.get(n, []):
-        prod = 1
-        for r, g in zip(rad, gs):
-            prod *= r
-            assert n % (r * g) == 0, (n, rad, gs)
-        assert prod == n and fpw * max(n // (r * g) for r, g in zip(rad, gs)) <= 1024, (n, rad, gs, fpw)
-        out.append((0.0, rad, gs, fpw, tw))
-    return out
+    return out[:per_size]
 
 
 # hand-added candidates the filters above reject (register estimate too cautious)

@@ -25,7 +25,8 @@ def five_smooth(n):
     return n == 1
 
 
-SMOOTH = [n for n in range(6, 10001, 2) if n & (n - 1) and five_smooth(n)]
+SMOOTH = [n for n in range(6, 10001, 2) if n & (n - 1) and five_smooth(n)] + \
+         [700, 1100, 1300, 1400, 1700, 1900, 2100, 2300, 3500, 4900, 6500, 7000, 7700, 9500, 9900]   # prime radices 7 ... 23
 t0 = time.time()
 ncase = 0
 worst = 0.0
