@@ -30,7 +30,9 @@ struct MPass {
     static constexpr int R = R_, G = G_;
 };
 
-// TW: where a thread's twiddles live -- 0 registers, 1 per-thread rows of an LDS table.
+// TW: where a thread's twiddles live -- 0 registers; 1 per-thread rows of an LDS table; 2 registers for pass 0
+// (every thread's are different) and, for the later passes, one LDS table per pass indexed by [k][ntail] (threads
+// with the same ntail share an entry: (R_i - 1) S_i entries, a few percent of N).
 template <int N_, int FPW_, int TW_, class... Ps>
 struct MixPlan {
     static constexpr int N = N_, FPW = FPW_, TW = TW_;
@@ -78,9 +80,18 @@ struct MixPlan {
         return o;
     }
     static constexpr int TW_TABLE = tw_table_offset(F - 1);
+    static constexpr int tw2_offset(int i)        // TW == 2: first entry of pass i >= 1
+    {
+        int o = 0;
+        for (int j = 1; j < i; ++j) o += (Rs[j] - 1) * S(j);
+        return o;
+    }
+    static constexpr int TW2_TABLE = tw2_offset(F - 1);
+    static constexpr int NTW_REG = TW == 0 ? NTW : TW == 2 ? Gs[0] * (Rs[0] - 1) : 0;        // twiddle registers
+    static constexpr int TABLE_ENTRIES = TW == 1 ? TW_TABLE : TW == 2 ? TW2_TABLE : 0;       // twiddles in LDS
     static constexpr int PPT0 = Rs[0] * Gs[0];
     static constexpr int NRAW = (PPT0 + 1) / 2;          // raw registers: two samples each
-    static constexpr int LDS_BYTES = (FPW * LDS_CPX + (TW == 1 ? TW_TABLE : 0)) * 8;
+    static constexpr int LDS_BYTES = (FPW * LDS_CPX + TABLE_ENTRIES) * 8;
     // window values: the thread's registers, or (room permitting) LDS when it has many of them or few registers
     static constexpr bool WLDS = LDS_BYTES + 4 * N <= 160 * 1024;
     static constexpr int PPTL = Rs[F - 1] * Gs[F - 1];

@@ -415,8 +415,10 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT,
                     "Number of bins must be a positive even number.");
     const int variant = static_cast<int>((cfg->flags >> 8) & 0xffu);
-    const bool fourstep = rpf::fourstep_supported(cfg->N) && variant == 0;
-    const bool mixed = rpf::mixed_supported(cfg->N, variant) && !(cfg->flags & RPF_FLAG_NO_MIXED_RADIX);
+    // (asking for the fused four-step kernel is asking for the four-step path)
+    const bool mixed = rpf::mixed_supported(cfg->N, variant) &&
+                       !(cfg->flags & (RPF_FLAG_NO_MIXED_RADIX | RPF_FLAG_FOURSTEP_FUSED));
+    const bool fourstep = !mixed && rpf::fourstep_supported(cfg->N) && variant == 0;
     const bool bluestein = !mixed && rpf::bluestein_supported(cfg->N) && variant == 0;
     const bool bigblu = !mixed && rpf::bigblu_supported(cfg->N) && variant == 0;
     const bool tuned = fourstep || mixed || bluestein || bigblu || rpf::kernel_supported(cfg->N, variant);

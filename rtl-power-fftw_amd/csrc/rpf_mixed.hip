@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kMixedWG) void mixed_kernel(const uint8_t* __restri
 template <class PL, int I>
 __device__ __forceinline__ void plan_load_twiddles(int t, const cf* __restrict__ twN, cf* tw)
 {
-    if constexpr (I < PL::F - 1) {
+    if constexpr (I < PL::F - 1 && (PL::TW == 0 || I == 0)) {
         if (t < PL::TPF(I)) {
 #pragma unroll
             for (int g = 0; g < PL::G(I); ++g)
@@ -202,6 +202,17 @@ __device__ __forceinline__ void plan_fill_table(int tid, const cf* __restrict__ 
     }
 }
 
+// TW == 2: pass I >= 1's block is [k - 1][ntail]
+template <class PL, int I>
+__device__ __forceinline__ void plan_fill_shared_table(int tid, const cf* __restrict__ twN, cf* table)
+{
+    if constexpr (I < PL::F - 1) {
+        constexpr int S = PL::S(I), n = (PL::R(I) - 1) * S;
+        for (int i = tid; i < n; i += PL::WG) table[PL::tw2_offset(I) + i] = twN[PL::D(I) * (i % S) * (i / S + 1)];
+        plan_fill_shared_table<PL, I + 1>(tid, twN, table);
+    }
+}
+
 template <class PL, int I>
 __device__ __forceinline__ void plan_later_passes(int t, cf* slab, const cf* tw, const cf* table, double* acc, bool active)
 {
@@ -222,39 +233,42 @@ __device__ __forceinline__ void plan_later_passes(int t, cf* slab, const cf* tw,
                         mix_butterfly<PL, I>(v, tw + PL::tw_offset(I) + g * (R - 1));
                     } else {
                         cf twj[R - 1];
+                        const cf* const row = PL::TW == 1 ? table + PL::tw_table_offset(I) + g * (R - 1) * PL::TPF(I) + t
+                                                          : table + PL::tw2_offset(I) + (t + g * PL::TPF(I)) % PL::S(I);
 #pragma unroll
-                        for (int k = 0; k < R - 1; ++k)
-                            twj[k] = table[PL::tw_table_offset(I) + (g * (R - 1) + k) * PL::TPF(I) + t];
+                        for (int k = 0; k < R - 1; ++k) twj[k] = row[k * (PL::TW == 1 ? PL::TPF(I) : PL::S(I))];
                         mix_butterfly<PL, I>(v, twj);
                     }
                     mix_store<PL, I>(sb, v, slab);
                 }
             }
         }
-        exchange_sync<true>();       // after the last pass: the next frame's pass 0 overwrites the slab
+        if constexpr (!last) exchange_sync<true>();
         plan_later_passes<PL, I + 1>(t, slab, tw, table, acc, active);
     }
 }
 
-// pass 0 of butterflies G, G+1, ... of a thread: unpack from the raw registers, transform, store
+// pass 0 of butterflies G, G+1, ... of a thread: unpack from the raw registers, transform, store.
+// (Measured and dropped: computing pass 0 into registers BEFORE the barrier that waits for the previous frame's
+// last pass to leave the slab, storing after it -- 0 ... -5 % even where one workgroup has the CU to itself.)
 template <class PL, bool WINDOW, int G>
 __device__ __forceinline__ void plan_first_pass(int t, cf* slab, const cf* tw, const cf* table, const uint32_t* raw,
                                                 const float* sgn, const float* wsgn)
 {
     if constexpr (G < PL::G(0)) {
         constexpr int R0 = PL::R(0), T0 = PL::TPF(0);
-        cf v[R0];
-        if constexpr (WINDOW && PL::WLDS) mix_unpack<PL, WINDOW, G * R0, PL::S(0)>(raw, sgn[G], wsgn + G * T0, v);
-        else mix_unpack<PL, WINDOW, G * R0>(raw, sgn[G], wsgn + (WINDOW ? G * R0 : 0), v);
-        if constexpr (PL::TW == 0) {
-            mix_butterfly<PL, 0>(v, tw + G * (R0 - 1));
+        cf vg[R0];
+        if constexpr (WINDOW && PL::WLDS) mix_unpack<PL, WINDOW, G * R0, PL::S(0)>(raw, sgn[G], wsgn + G * T0, vg);
+        else mix_unpack<PL, WINDOW, G * R0>(raw, sgn[G], wsgn + (WINDOW ? G * R0 : 0), vg);
+        if constexpr (PL::TW != 1) {
+            mix_butterfly<PL, 0>(vg, tw + G * (R0 - 1));
         } else {
             cf twj[R0 - 1];
 #pragma unroll
             for (int k = 0; k < R0 - 1; ++k) twj[k] = table[(G * (R0 - 1) + k) * T0 + t];
-            mix_butterfly<PL, 0>(v, twj);
+            mix_butterfly<PL, 0>(vg, twj);
         }
-        mix_store<PL, 0>(mix_slot_base<PL, 0>(t, G), v, slab);
+        mix_store<PL, 0>(mix_slot_base<PL, 0>(t, G), vg, slab);
         plan_first_pass<PL, WINDOW, G + 1>(t, slab, tw, table, raw, sgn, wsgn);
     }
 }
@@ -274,13 +288,14 @@ __global__ __launch_bounds__(PL::WG) void mixed_plan_kernel(const uint8_t* __res
     cf* const table = reinterpret_cast<cf*>(smem) + PL::FPW * PL::LDS_CPX;
     const bool in0 = T0 == PL::TPFMAX || t < T0;
 
-    cf tw[PL::TW == 0 ? (PL::NTW > 0 ? PL::NTW : 1) : 1];
-    if constexpr (PL::TW == 0) plan_load_twiddles<PL, 0>(t, twN, tw);
-    else plan_fill_table<PL, 0>(tid, twN, table);
+    cf tw[PL::NTW_REG > 0 ? PL::NTW_REG : 1];
+    if constexpr (PL::TW != 1) plan_load_twiddles<PL, 0>(t, twN, tw);
+    if constexpr (PL::TW == 1) plan_fill_table<PL, 0>(tid, twN, table);
+    if constexpr (PL::TW == 2) plan_fill_shared_table<PL, 1>(tid, twN, table);
 
     float sgn[G0];
     float wsgn[WINDOW && !PL::WLDS ? PL::PPT0 : 1];
-    float* const wlds = reinterpret_cast<float*>(table + (PL::TW == 1 ? PL::TW_TABLE : 0));   // window[n] (-1)^n
+    float* const wlds = reinterpret_cast<float*>(table + PL::TABLE_ENTRIES);   // window[n] (-1)^n
 #pragma unroll
     for (int g = 0; g < G0; ++g) sgn[g] = ((t + g * T0) & 1) ? -1.0f : 1.0f;
     if constexpr (WINDOW && PL::WLDS) {
@@ -319,6 +334,7 @@ __global__ __launch_bounds__(PL::WG) void mixed_plan_kernel(const uint8_t* __res
 #pragma unroll 1
     for (; fb < nframes; fb += stride) {
         const bool active = (fb + fs) < nframes;
+        exchange_sync<true>();                   // the previous frame's last pass has left the slab
         if (in0) {
             plan_first_pass<PL, WINDOW, 0>(t, slab, tw, table, raw, sgn, WINDOW && PL::WLDS ? wlds + t : wsgn);
             load_raw(fb + stride + fs);          // lands while the later passes run
@@ -353,7 +369,7 @@ struct PlanEntry {
 template <class PL>
 constexpr int plan_lds_bytes(bool windowed)
 {
-    return (PL::FPW * PL::LDS_CPX + (PL::TW == 1 ? PL::TW_TABLE : 0)) * (int)sizeof(cf) +
+    return PL::LDS_BYTES +
            (windowed && PL::WLDS ? PL::N * (int)sizeof(float) : 0);
 }
 template <class PL>
@@ -415,9 +431,9 @@ int lds_bytes(int N)       // [frame slots][2 buffers + accumulators] + the twid
 
 }  // namespace
 
-// even N whose frame fits one workgroup's LDS, only prime factors 2, 3, 5, not a power of two (those
-// are K1's): a planned kernel for the sizes in kPlans (up to 10000 bins), the Stockham kernel for the
-// rest (up to 5120 bins).  variant != 0 (tuning build): another plan of the same size; 100 = the
+// even N whose frame fits one workgroup's LDS: a planned kernel for the sizes in kPlans (up to 10000
+// bins, and 16384 -- the one power of two K1 cannot hold and the four-step kernels serve at half the
+// rate), the Stockham kernel for the other sizes with only prime factors 2, 3, 5 up to 5120 bins.  variant != 0 (tuning build): another plan of the same size; 100 = the
 // Stockham kernel for a size that has a plan.
 #ifdef RPF_TUNING
 constexpr int kStockhamVariant = 100;
@@ -425,11 +441,8 @@ constexpr int kStockhamVariant = 100;
 bool mixed_supported(int N, int variant)
 {
     if (N < 2 || (N & 1)) return false;
-#ifdef RPF_TUNING
-    if (variant != 0 && find_plan(N, variant)) return true;      // (candidates for K1's sizes can be timed, too)
-#endif
+    if (find_plan(N, variant)) return true;       // (16384 is one of these; the tuning build can time K1's sizes, too)
     if ((N & (N - 1)) == 0) return false;
-    if (find_plan(N, variant)) return true;
 #ifndef RPF_TUNING
     if (variant != 0) return false;
 #else

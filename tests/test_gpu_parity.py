@@ -125,7 +125,7 @@ def test_non_power_of_two_sizes_match_oracle(N, windowed, torch_dev):
 
 @pytest.mark.parametrize("N", [6, 10, 12, 50, 90, 96, 100, 108, 140, 150, 250, 384, 500, 600, 700, 750, 1000, 1100, 1200, 1300,
                                1458, 1500, 1536, 1700, 1900, 2000, 2300, 2430, 3000, 3600, 3750, 4000, 4050, 4374, 4500, 5000,
-                               5120, 6000, 6250, 6400, 7000, 7500, 7800, 8000, 9000, 9216, 9500, 9720, 9900, 10000])
+                               5120, 6000, 6250, 6400, 7000, 7500, 7800, 8000, 9000, 9216, 9500, 9720, 9900, 10000, 16384])
 def test_mixed_radix_sizes_match_oracle_and_bluestein(N, torch_dev):
     """Even N <= 10000 with small prime factors (the "round" sizes, the man page's -b 500 among
     them; 2, 3, 5 and -- for the multiples of 100 -- 7 ... 23): LDS mixed-radix kernels (rpf_mixed.hip: the planned kernel for the sizes of
@@ -160,11 +160,12 @@ def test_four_step_sizes_match_oracle(N, torch_dev):
     stream = rpf.synth.uniform_iq(44 + N % 97, N * R + 1000)
     for windowed in (False, True):
         w = rpf.synth.hann_window(N) + np.float32(0.25) if windowed else None
-        with rpf.Datastore(rpf.Params(N=N, window=windowed, repeats=R), w) as ds:
+        # (16384 also fits the planned LDS kernel, which is what runs by default: test_mixed_radix_...)
+        with rpf.Datastore(rpf.Params(N=N, window=windowed, repeats=R), w, flags=rpf._lib.FLAG_NO_MIXED_RADIX) as ds:
             got, n = run_device(ds, stream, R, torch_dev)
             host, done = ds.accumulate(stream, R)
         with rpf.Datastore(rpf.Params(N=N, window=windowed, repeats=R), w,
-                           flags=rpf._lib.FLAG_NO_LDS_DMA) as ds2:
+                           flags=rpf._lib.FLAG_NO_LDS_DMA | rpf._lib.FLAG_NO_MIXED_RADIX) as ds2:
             got_nodma, _ = run_device(ds2, stream, R, torch_dev)
         assert n == done == R
         assert np.array_equal(got, got_nodma)
@@ -188,7 +189,8 @@ def test_fused_four_step_equals_the_two_kernel_path(N, torch_dev):
     for window in (None, w):
         with rpf.Datastore(rpf.Params(N=N, window=window is not None, repeats=R), window,
                            flags=rpf._lib.FLAG_FOURSTEP_FUSED) as fused, \
-                rpf.Datastore(rpf.Params(N=N, window=window is not None, repeats=R), window) as plain:
+                rpf.Datastore(rpf.Params(N=N, window=window is not None, repeats=R), window,
+                              flags=rpf._lib.FLAG_NO_MIXED_RADIX) as plain:
             for frames in (R, 1, 262144 // N, 8 * (262144 // N) + 1, R):
                 outs = []
                 for ds in (fused, plain):
@@ -211,11 +213,13 @@ def test_large_non_power_of_two_sizes_match_oracle(N, torch_dev):
     stream = rpf.synth.uniform_iq(321 + N % 89, N * R + N // 2 + 2)
     for windowed in (False, True):
         w = rpf.synth.hann_window(N) + np.float32(0.25) if windowed else None
-        with rpf.Datastore(rpf.Params(N=N, window=windowed, repeats=R, buf_length=1 << 20), w) as ds:
+        # (5000 and 10000 have a mixed-radix kernel of their own, which is what runs by default)
+        with rpf.Datastore(rpf.Params(N=N, window=windowed, repeats=R, buf_length=1 << 20), w,
+                           flags=rpf._lib.FLAG_NO_MIXED_RADIX) as ds:
             got, n = run_device(ds, stream, R, torch_dev)
             host, done = ds.accumulate(stream, R)          # 1 MB buffers: frames straddle them
         with rpf.Datastore(rpf.Params(N=N, window=windowed, repeats=R), w,
-                           flags=rpf._lib.FLAG_NO_LDS_DMA) as ds2:
+                           flags=rpf._lib.FLAG_NO_LDS_DMA | rpf._lib.FLAG_NO_MIXED_RADIX) as ds2:
             got_nodma, _ = run_device(ds2, stream, R, torch_dev)
         assert n == done == R
         assert np.array_equal(got, got_nodma)
@@ -224,7 +228,7 @@ def test_large_non_power_of_two_sizes_match_oracle(N, torch_dev):
             import torch
             d_in = torch.from_numpy(np.ascontiguousarray(stream)).to(torch_dev)
             d_out = torch.empty(N, dtype=torch.float64, device=torch_dev)
-            with rpf.Datastore(rpf.Params(N=N, repeats=R)) as ds3:
+            with rpf.Datastore(rpf.Params(N=N, repeats=R), flags=rpf._lib.FLAG_NO_MIXED_RADIX) as ds3:
                 st = torch.cuda.current_stream().cuda_stream
                 assert ds3.device_fused(d_in.data_ptr(), stream.size, R, st) == R
                 ds3.device_reduce(d_out.data_ptr(), st)

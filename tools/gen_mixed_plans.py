@@ -30,6 +30,7 @@ SIZES = [100, 120, 150, 160, 200, 240, 250, 300, 320, 360, 400, 450, 480, 500, 6
          4600, 4900, 5100, 5200, 5500, 5600, 5700, 6300, 6500, 6600, 6800, 6900, 7000, 7600, 7700, 7800, 8400, 8500, 8800,
          9100, 9200, 9500, 9800, 9900]
 LDS_LIMIT = 160 * 1024
+TW_MODES = (0, 1)        # the sizes searched so far were searched with these; "search2" adds mode 2
 
 
 def factorisations(n, maxf=4):
@@ -76,14 +77,22 @@ def plans_of(n, ratio=0.74):
 def lds_bytes(n, rad, gs, fpw, tw):
     rlast = rad[-1]
     cpx = n + n // rlast if rlast % 2 == 0 else n
-    table = sum(g * (r - 1) * (n // (r * g)) for r, g in zip(rad[:-1], gs[:-1])) if tw else 0
+    table = 0
+    if tw == 1:
+        table = sum(g * (r - 1) * (n // (r * g)) for r, g in zip(rad[:-1], gs[:-1]))
+    elif tw == 2:
+        s = n
+        for i, r in enumerate(rad[:-1]):
+            s //= r                       # S_i
+            if i >= 1:
+                table += (r - 1) * s
     return (fpw * cpx + table) * 8
 
 
 def vgprs(rad, gs, tw):
     pts = 2 * max(r * g for r, g in zip(rad, gs))
-    twr = 0 if tw else 2 * sum(g * (r - 1) for r, g in zip(rad[:-1], gs[:-1]))
-    return pts + twr + 2 * rad[-1] * gs[-1] + rad[0] * gs[0] + 30
+    twr = {0: 2 * sum(g * (r - 1) for r, g in zip(rad[:-1], gs[:-1])), 1: 0, 2: 2 * gs[0] * (rad[0] - 1)}[tw]
+    return pts + twr + 2 * rad[-1] * gs[-1] + (rad[0] * gs[0] + 1) // 2 + 24
 
 
 def candidates(n, per_size=18):
@@ -126,7 +135,9 @@ def _candidates(n, per_size, ratio):
                     pick.append(best)
             got = False
             for fpw in pick:
-                for tw in (0, 1):
+                for tw in TW_MODES:
+                    if tw == 2 and len(rad) < 3:
+                        continue          # (two passes: the same as registers)
                     wg = fpw * tmax
                     v = vgprs(rad, gs, tw)
                     waves_per_simd = -(-wg // 64) / 4.0
@@ -144,7 +155,13 @@ def _candidates(n, per_size, ratio):
 
 
 # hand-added candidates the filters above reject (register estimate too cautious)
-EXTRA = {9000: [((10, 10, 10, 9), (1, 1, 1, 1), 1, 0), ((9, 10, 10, 10), (1, 1, 1, 1), 1, 0),
+EXTRA = {8192: [((16, 8, 8, 8), (2, 4, 4, 4), 1, 2), ((16, 8, 8, 8), (2, 4, 4, 4), 2, 2), ((8, 8, 8, 16), (4, 4, 4, 2), 1, 2),
+                ((8, 8, 8, 16), (4, 4, 4, 2), 2, 0), ((8, 16, 8, 8), (4, 2, 4, 4), 1, 0), ((4, 8, 16, 16), (8, 4, 2, 2), 1, 2)],
+         16384: [((4, 16, 16, 16), (4, 1, 1, 1), 1, 2), ((8, 8, 16, 16), (2, 2, 1, 1), 1, 2), ((8, 16, 8, 16), (2, 1, 2, 1), 1, 2),
+                 ((16, 16, 4, 16), (1, 1, 4, 1), 1, 2), ((8, 16, 8, 16), (4, 2, 4, 2), 1, 2),
+                 ((16, 4, 16, 16), (2, 8, 2, 2), 1, 2), ((8, 8, 16, 16), (4, 4, 2, 2), 1, 2), ((16, 16, 4, 16), (2, 2, 8, 2), 1, 2),
+                 ((16, 8, 8, 16), (2, 4, 4, 2), 1, 2)],
+         9000: [((10, 10, 10, 9), (1, 1, 1, 1), 1, 0), ((9, 10, 10, 10), (1, 1, 1, 1), 1, 0),
                 ((10, 9, 10, 10), (1, 1, 1, 1), 1, 0), ((18, 20, 25), (1, 1, 1), 1, 0), ((25, 18, 20), (1, 1, 1), 1, 0)],
          6250: [((10, 25, 25), (1, 1, 1), 1, 0), ((25, 10, 25), (1, 1, 1), 1, 0), ((25, 25, 10), (1, 1, 1), 1, 0)],
          3750: [((10, 15, 25), (3, 2, 1), 2, 0), ((10, 15, 25), (3, 2, 1), 3, 0), ((6, 25, 25), (5, 1, 1), 2, 0),
@@ -168,6 +185,10 @@ def entry(n, rad, gs, fpw, tw, variant):
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "search"
     sizes = [int(a) for a in sys.argv[2:]] or SIZES
+    if mode.endswith("2"):
+        global TW_MODES
+        TW_MODES = (0, 1, 2)
+        mode = mode[:-1]
     if mode == "search":
         print("// generated by tools/gen_mixed_plans.py search -- tuning build only")
         for n in sizes:
