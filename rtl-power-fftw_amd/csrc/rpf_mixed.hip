@@ -1,5 +1,6 @@
 // rpf_mixed.hip -- KM: LDS-resident mixed-radix kernels for the "round" sizes people actually
-// type: even N <= 10000 with small prime factors (2, 3, 5; 7 ... 23 for multiples of 100) that are not powers of two
+// type: even N <= 16384 with small prime factors (2, 3, 5; 7 ... 23 for multiples of 100) that are not powers of
+// two -- and 16384 itself
 // (500 -- the man page's own example, doc/rtl_power_fftw.1.md:182 --, 1000, 1200, 2000, 3000,
 // 5000, 10000, ...).  Bluestein (KB) serves such sizes with two power-of-two transforms of 2-4 N
 // points each; a transform of the length itself costs a fifth of that.
@@ -431,7 +432,7 @@ int lds_bytes(int N)       // [frame slots][2 buffers + accumulators] + the twid
 
 }  // namespace
 
-// even N whose frame fits one workgroup's LDS: a planned kernel for the sizes in kPlans (up to 10000
+// even N whose frame fits one workgroup's LDS: a planned kernel for the sizes in kPlans (up to 16000
 // bins, and 16384 -- the one power of two K1 cannot hold and the four-step kernels serve at half the
 // rate), the Stockham kernel for the other sizes with only prime factors 2, 3, 5 up to 5120 bins.  variant != 0 (tuning build): another plan of the same size; 100 = the
 // Stockham kernel for a size that has a plan.

@@ -31,6 +31,7 @@ SIZES = [100, 120, 150, 160, 200, 240, 250, 300, 320, 360, 400, 450, 480, 500, 6
          9100, 9200, 9500, 9800, 9900]
 LDS_LIMIT = 160 * 1024
 TW_MODES = (0, 1)        # the sizes searched so far were searched with these; "search2" adds mode 2
+MAXPPT = 25              # ... and up to 32 points per thread
 
 
 def factorisations(n, maxf=4):
@@ -55,8 +56,8 @@ def plans_of(n, ratio=0.74):
         f = len(rad)
         if f < 2:
             continue
-        opts = [[g for g in range(1, 9) if 8 <= r * g <= 25 and n % (r * g) == 0] or
-                [g for g in range(1, 9) if r * g <= 25 and n % (r * g) == 0][-1:] for r in rad]
+        opts = [[g for g in range(1, 9) if 8 <= r * g <= MAXPPT and n % (r * g) == 0] or
+                [g for g in range(1, 9) if r * g <= MAXPPT and n % (r * g) == 0][-1:] for r in rad]
         if any(not o for o in opts):
             continue
         for gs in itertools.product(*opts):
@@ -110,7 +111,7 @@ def candidates(n, per_size=18):
 def _candidates(n, per_size, ratio):
     out = []
     plans = plans_of(n, ratio)
-    for lo, hi, nshapes in ((0, 12, 2), (13, 16, 1), (17, 25, 2)):       # points per thread: light / middle / heavy
+    for lo, hi, nshapes in ((0, 12, 2), (13, 16, 1), (17, 25, 2), (26, 32, 2)):       # points per thread: light / middle / heavy
         seen_shapes = set()
         for cost, rad, gs, tpf, tmax in plans:
             ppt = max(r * g for r, g in zip(rad, gs))
@@ -186,8 +187,9 @@ def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "search"
     sizes = [int(a) for a in sys.argv[2:]] or SIZES
     if mode.endswith("2"):
-        global TW_MODES
+        global TW_MODES, MAXPPT
         TW_MODES = (0, 1, 2)
+        MAXPPT = 32
         mode = mode[:-1]
     if mode == "search":
         print("// generated by tools/gen_mixed_plans.py search -- tuning build only")
