@@ -10,7 +10,7 @@ timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "py
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
 timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/bench_20.json 2> $OUT/bench_20.err; echo "bench rc=$?"; cut -c1-400 $OUT/bench_20.json
 cd /tmp && export TMPDIR=/tmp
-SWEEP_NOWIN=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/km_trace -o km -- python $ROOT/tools/gpu_sweep.py 500:0 1000:0 2000:0 5000:0 > $OUT/km_trace.log 2>&1
+SWEEP_NOWIN=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/km_trace -o km -- python $ROOT/tools/gpu_sweep.py 500:0 1000:0 2000:0 5000:0 7000:0 10000:0 15000:0 16384:0 > $OUT/km_trace.log 2>&1
 cp $(find $OUT/km_trace -name 'km_kernel_stats.csv' | head -1) $OUT/km_kernel_stats.csv 2>/dev/null
 rm -rf $OUT/km_trace
 cd $ROOT
