@@ -480,7 +480,7 @@ hipError_t plan_mixed(int N, int variant, bool windowed, int device, LaunchInfo*
 hipError_t launch_mixed(int N, int variant, const uint8_t* d_stream, long nframes, const cf* d_twN, const float* d_window,
                         double* d_partial, int grid, hipStream_t stream, LaunchInfo* li)
 {
-    if (!mixed_supported(N, variant) || grid < 1) return hipErrorInvalidValue;
+    if (!mixed_supported(N, variant) || grid < 1 || nframes < 1) return hipErrorInvalidValue;
     int wg = kMixedWG, fpw = 0, lds = 0;
     if (const PlanEntry* pe = find_plan(N, variant)) {
         wg = pe->wg, fpw = pe->fpw, lds = d_window ? pe->lds_windowed : pe->lds;
