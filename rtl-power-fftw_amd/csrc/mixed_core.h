@@ -173,6 +173,53 @@ RPF_HD void mix_unpack(const uint32_t* raw, float sgn, const float* wsgn, cf* v)
     }
 }
 
+// Split form (N = P M, one workgroup per residue p: X[p + P k] = FFT_M(x'_p)[k]): pass-0 input
+//   x'_p[n] = ( sum_{j<P} x[n + j M] W_P^{j p} ) W_N^{n p},     n = ntail + n1 S_0,
+//   W_N^{n p} = W_N^{ntail p} (folded into the butterfly's output twiddles) * W_N^{n1 S_0 p} (mid[n1], the same for
+//   every thread of the workgroup).
+// The sum runs section by section (j = 0, 1, ...: the j-th M samples of the frame), so that only one section's
+// raw registers (and the next one's, in flight) are live whatever P is:
+//   mix_split_accumulate<J == 0>: v[i] (+)= x_j[i] W_P^{j p} for the thread's PPT0 samples i = g R_0 + n1
+//     raw: the section's samples, one per register (the two buffers of the pipeline are loaded and consumed
+//     without a packing step in between, which would wait for the loads where they are issued);
+//     w: its window values at ntail = t (plain, WINDOW only); wpj = W_P^{j p}
+//   mix_split_mid: v[g R_0 + n1] *= mid[n1]
+// M is even, so (-1)^(n + j M) does not depend on j.
+template <class PL, bool WINDOW, bool FIRST, int I = 0>
+RPF_HD void mix_split_accumulate(const uint32_t* raw, const float* sgn, const float* w, cf wpj, cf* v)
+{
+    if constexpr (I < PL::PPT0) {
+        constexpr int g = I / PL::R(0), n1 = I % PL::R(0);
+        const float sg = ((n1 * PL::S(0)) & 1) ? -sgn[g] : sgn[g];
+        const cf f = iq_plus_2p23(raw[I]);
+        cf x;
+        if constexpr (WINDOW) x = (f - (kTwo23 + 127.0f)) * (w[g * PL::TPF(0) + n1 * PL::S(0)] * sg);   // one rounding
+        else x = f * sg - (kTwo23 + 127.0f) * sg;                                                          // exact
+        if constexpr (FIRST) v[I] = x;
+        else v[I] = v[I] + cmul_k(x, wpj);          // (wpj, mid: the same in every lane -- scalar registers)
+        mix_split_accumulate<PL, WINDOW, FIRST, I + 1>(raw, sgn, w, wpj, v);
+    }
+}
+template <class PL, int I = 0>
+RPF_HD void mix_split_mid(cf* v, const cf* mid)
+{
+    if constexpr (I < PL::PPT0) {
+        v[I] = cmul_k(v[I], mid[I % PL::R(0)]);
+        mix_split_mid<PL, I + 1>(v, mid);
+    }
+}
+
+// pass-0 butterfly of the split form: every output, k = 0 included, carries the factor W_N^{ntail p}:
+// tw[0] = that factor, tw[k] = factor * W_M^{ntail k}
+template <class PL>
+RPF_HD void mix_butterfly_split(cf* v, const cf* tw)
+{
+    constexpr int R = PL::R(0);
+    SmallDft<R>::run(v);
+#pragma unroll
+    for (int k = 0; k < R; ++k) v[k] = cmul(v[k], tw[k]);
+}
+
 template <class PL, int I>
 RPF_HD void mix_butterfly(cf* v, const cf* tw)
 {

@@ -192,14 +192,14 @@ int launch_transform(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, hi
         *nslots = rpf::bigblu_partial_slots(e->N);
         return RPF_OK;
     }
-    const int64_t wanted = (nframes + e->plan.fpw - 1) / e->plan.fpw;
-    const int grid = static_cast<int>(std::min<int64_t>(e->plan.grid, wanted));
-    if (e->mixed) {
-        HIP_TRY(e, rpf::launch_mixed(e->N, e->variant, d_frames, nframes, e->d_twiddles, e->d_window, e->d_partial, grid, stream,
-                                     &e->last));
-        *nslots = grid;
+    if (e->mixed) {       // (trims the grid to the frames itself: the split form needs a multiple of its factor)
+        HIP_TRY(e, rpf::launch_mixed(e->N, e->variant, d_frames, nframes, e->d_twiddles, e->d_window, e->d_partial,
+                                     e->plan.grid, stream, &e->last));
+        *nslots = e->last.slots ? e->last.slots : e->last.grid;
         return RPF_OK;
     }
+    const int64_t wanted = (nframes + e->plan.fpw - 1) / e->plan.fpw;
+    const int grid = static_cast<int>(std::min<int64_t>(e->plan.grid, wanted));
     if (e->bluestein) {
         HIP_TRY(e, rpf::launch_bluestein(e->N, d_frames, nframes, e->d_twiddles, e->d_chirp, e->d_bhat,
                                          e->d_partial, grid, stream, &e->last));

@@ -17,6 +17,7 @@ struct LaunchInfo {
     int fpw = 0;         // frames processed concurrently by one workgroup
     int lds_bytes = 0;   // dynamic LDS per workgroup
     bool partial_f32 = false;   // partial spectra are float32 (tuning variants), else f64
+    int slots = 0;       // partial spectra written (0: one per workgroup)
 };
 
 // Is there a fused kernel for N bins (tuning variant vid, 0 = default)?

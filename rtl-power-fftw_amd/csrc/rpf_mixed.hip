@@ -175,7 +175,8 @@ __global__ __launch_bounds__(kMixedWG) void mixed_kernel(const uint8_t* __restri
 // (two or three passes where the Stockham kernels above take four to seven), twiddles and
 // accumulators in registers for the whole launch, the next frame's samples prefetched into
 // registers while the current one is transformed.
-template <class PL, int I>
+// TS: stride of W_{PL::N}^k in the table (1; P in the split form, whose table is W_{P N})
+template <class PL, int I, int TS = 1>
 __device__ __forceinline__ void plan_load_twiddles(int t, const cf* __restrict__ twN, cf* tw)
 {
     if constexpr (I < PL::F - 1 && (PL::TW == 0 || I == 0)) {
@@ -184,9 +185,9 @@ __device__ __forceinline__ void plan_load_twiddles(int t, const cf* __restrict__
             for (int g = 0; g < PL::G(I); ++g)
 #pragma unroll
                 for (int k = 1; k < PL::R(I); ++k)
-                    tw[PL::tw_offset(I) + g * (PL::R(I) - 1) + k - 1] = twN[mix_twiddle_index<PL, I>(t, g, k)];
+                    tw[PL::tw_offset(I) + g * (PL::R(I) - 1) + k - 1] = twN[TS * mix_twiddle_index<PL, I>(t, g, k)];
         }
-        plan_load_twiddles<PL, I + 1>(t, twN, tw);
+        plan_load_twiddles<PL, I + 1, TS>(t, twN, tw);
     }
 }
 // LDS table: pass I's block is [g][k - 1][t], so the threads of a wave read consecutive entries
@@ -204,13 +205,13 @@ __device__ __forceinline__ void plan_fill_table(int tid, const cf* __restrict__ 
 }
 
 // TW == 2: pass I >= 1's block is [k - 1][ntail]
-template <class PL, int I>
+template <class PL, int I, int TS = 1>
 __device__ __forceinline__ void plan_fill_shared_table(int tid, const cf* __restrict__ twN, cf* table)
 {
     if constexpr (I < PL::F - 1) {
         constexpr int S = PL::S(I), n = (PL::R(I) - 1) * S;
-        for (int i = tid; i < n; i += PL::WG) table[PL::tw2_offset(I) + i] = twN[PL::D(I) * (i % S) * (i / S + 1)];
-        plan_fill_shared_table<PL, I + 1>(tid, twN, table);
+        for (int i = tid; i < n; i += PL::WG) table[PL::tw2_offset(I) + i] = twN[TS * (PL::D(I) * (i % S) * (i / S + 1))];
+        plan_fill_shared_table<PL, I + 1, TS>(tid, twN, table);
     }
 }
 
@@ -361,11 +362,140 @@ __global__ __launch_bounds__(PL::WG) void mixed_plan_kernel(const uint8_t* __res
     }
 }
 
+
+// ---- split form: N = P M, M one of the planned lengths ------------------------------------------
+// Workgroup b computes the residue p = b mod P of the spectrum, X[p + P k] = FFT_M(x'_p)[k] with
+// x'_p[n] = (sum_j x[n + j M] W_P^{jp}) W_N^{np} (mixed_core.h, mix_unpack_split): the first radix-P
+// pass of a decimation-in-frequency transform, evaluated for one output only, so nothing but the raw
+// bytes ever crosses workgroups -- the P workgroups of a frame read the same 2N bytes (L2 / Infinity
+// Cache serve the repeats) where the four-step kernels move 16 bytes of intermediate per sample.
+// P = 2 ... 5 costs 5 P extra instructions per point; the sizes between 20000 and 80000 bins that
+// large Bluestein served at 0.04 Tsample/s.
+// sections J, J + 1, ... of the frame: while section J is unpacked and added to v, section J + 1 is in flight
+// into the other raw buffer (and, after the last one, section 0 of the workgroup's next frame)
+template <class PL, int P, bool WINDOW, int J, class Load>
+__device__ __forceinline__ void split_sections(uint32_t (*raw)[PL::PPT0], const float* sgn, const float* w, const cf* wp, cf* v,
+                                               const Load& load_next_frame_section0, const uint8_t* frame)
+{
+    if constexpr (J < P) {
+        constexpr int T0 = PL::TPF(0), R0 = PL::R(0), S0 = PL::S(0);
+        if constexpr (J + 1 < P) {
+            const uint8_t* const base = frame + 2L * (J + 1) * PL::N;
+#pragma unroll
+            for (int i = 0; i < PL::PPT0; ++i)
+                raw[(J + 1) & 1][i] = *reinterpret_cast<const uint16_t*>(base + 2 * ((i / R0) * T0 + (i % R0) * S0));
+        } else {
+            load_next_frame_section0(raw[(J + 1) & 1]);
+        }
+        mix_split_accumulate<PL, WINDOW, J == 0>(raw[J & 1], sgn, WINDOW ? w + J * PL::N : w, wp[J], v);
+        split_sections<PL, P, WINDOW, J + 1>(raw, sgn, w, wp, v, load_next_frame_section0, frame);
+    }
+}
+
+template <class PL, int P, bool WINDOW>
+__global__ __launch_bounds__(PL::WG) void mixed_split_kernel(const uint8_t* __restrict__ stream, long nframes,
+                                                            const cf* __restrict__ twN, const float* __restrict__ window,
+                                                            double* __restrict__ partial)
+{
+    static_assert(PL::TW != 1 && PL::FPW == 1 && PL::N % 2 == 0, "pass-0 twiddles in registers, one frame slot, even M");
+    constexpr int M = PL::N, N = P * M, R0 = PL::R(0), G0 = PL::G(0), T0 = PL::TPF(0), S0 = PL::S(0);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x;
+    // The P workgroups of a frame read the same bytes: put them on one XCD (workgroups go to the 8 XCDs round-robin by
+    // index), so that its L2 fetches the frame once and serves the others -- when the grid is a multiple of 8 P;
+    // any grid that is a multiple of P works with the plain mapping.
+    const bool xcd_local = gridDim.x % (8 * P) == 0;
+    const int q = blockIdx.x / 8;
+    const int p = xcd_local ? q % P : blockIdx.x % P;
+    const int group = xcd_local ? (blockIdx.x % 8) + 8 * (q / P) : blockIdx.x / P;
+    cf* const slab = reinterpret_cast<cf*>(smem);
+    cf* const table = reinterpret_cast<cf*>(smem) + PL::LDS_CPX;
+    const bool in0 = T0 == PL::TPFMAX || t < T0;
+
+    cf tw[PL::NTW_REG > 0 ? PL::NTW_REG : 1];                    // (pass 0's block is unused here)
+    plan_load_twiddles<PL, 0, P>(t, twN, tw);
+    if constexpr (PL::TW == 2) plan_fill_shared_table<PL, 1, P>(t, twN, table);
+    // pass 0: output k of the butterfly with ntail carries W_N^{ntail p} W_M^{ntail k} = W_N^{ntail (p + P k)}
+    cf tw0[G0 * R0];
+    float sgn[G0];
+#pragma unroll
+    for (int g = 0; g < G0; ++g) {
+        const int ntail = t + g * T0;
+        sgn[g] = (ntail & 1) ? -1.0f : 1.0f;
+#pragma unroll
+        for (int k = 0; k < R0; ++k) tw0[g * R0 + k] = in0 ? twN[(static_cast<long>(ntail) * (p + P * k)) % N] : cf{0.0f, 0.0f};
+    }
+    cf wp[P], mid[R0];                                           // the same for every thread of the workgroup
+#pragma unroll
+    for (int j = 0; j < P; ++j) wp[j] = twN[(static_cast<long>(j) * p * M) % N];
+#pragma unroll
+    for (int n1 = 0; n1 < R0; ++n1) mid[n1] = twN[(static_cast<long>(n1) * S0 * p) % N];
+    double acc[PL::PPTL];
+#pragma unroll
+    for (int a = 0; a < PL::PPTL; ++a) acc[a] = 0.0;
+
+    uint32_t raw[2][PL::PPT0];          // one sample per register (mix_split_accumulate)
+    auto load_section0 = [&](long frame, uint32_t* dst) {
+        const uint8_t* const base = stream + (frame < nframes ? frame : nframes - 1) * (2L * N) + 2 * t;
+#pragma unroll
+        for (int i = 0; i < PL::PPT0; ++i) dst[i] = *reinterpret_cast<const uint16_t*>(base + 2 * ((i / R0) * T0 + (i % R0) * S0));
+    };
+    const long stride = gridDim.x / P;
+    long fb = group;
+    // section j of a frame lives in raw[j & 1]; the last section's turn puts the next frame's section 0 into
+    // raw[P & 1] -- for odd P that is raw[1], moved to raw[0] at the top of the next frame (long landed by then)
+    if (in0) load_section0(fb, raw[P & 1]);
+    __syncthreads();
+#pragma unroll 1
+    for (; fb < nframes; fb += stride) {
+        cf v[PL::PPT0];
+        if (in0) {
+            if constexpr (P % 2 == 1) {
+#pragma unroll
+                for (int r = 0; r < PL::PPT0; ++r) raw[0][r] = raw[1][r];
+            }
+            const uint8_t* const frame = stream + fb * (2L * N) + 2 * t;
+            // (opaque per frame: otherwise the compiler hoists the loop-invariant window loads out of the frame
+            // loop and spills them)
+            const float* w = window + t;
+            if constexpr (WINDOW) asm volatile("" : "+v"(w));
+            const long next = fb + stride;
+            auto next0 = [&](uint32_t* dst) { load_section0(next, dst); };
+            split_sections<PL, P, WINDOW, 0>(raw, sgn, w, wp, v, next0, frame);
+            mix_split_mid<PL>(v, mid);
+        }
+        exchange_sync<true>();                   // the previous frame's last pass has left the slab
+        if (in0) {
+#pragma unroll
+            for (int g = 0; g < G0; ++g) {
+                mix_butterfly_split<PL>(v + g * R0, tw0 + g * R0);
+                mix_store<PL, 0>(mix_slot_base<PL, 0>(t, g), v + g * R0, slab);
+            }
+        }
+        exchange_sync<true>();
+        plan_later_passes<PL, 1>(t, slab, tw, table, acc, true);
+    }
+    __syncthreads();
+    // the residue's M bins through LDS into natural order, then into the partial spectrum this workgroup shares
+    // with the P - 1 others of its group (disjoint bins)
+    double* const stage = reinterpret_cast<double*>(smem);
+    if (PL::TPF(PL::F - 1) == PL::TPFMAX || t < PL::TPF(PL::F - 1)) {
+#pragma unroll
+        for (int g = 0; g < PL::G(PL::F - 1); ++g)
+#pragma unroll
+            for (int k = 0; k < PL::RLAST; ++k) stage[mix_bin<PL>(t, g, k)] = acc[g * PL::RLAST + k];
+    }
+    __syncthreads();
+    double* const row = partial + static_cast<size_t>(group) * N + p;
+    for (int k = t; k < M; k += PL::WG) row[static_cast<size_t>(P) * k] = stage[k];
+}
+
 using PlanFn = void (*)(const uint8_t*, long, const cf*, const float*, double*);
 struct PlanEntry {
     int N, variant;
     PlanFn plain, windowed;
     int wg, fpw, lds, lds_windowed;
+    int split;          // 1, or the factor P of the split form (N = P x the plan's length)
 };
 template <class PL>
 constexpr int plan_lds_bytes(bool windowed)
@@ -377,7 +507,13 @@ template <class PL>
 constexpr PlanEntry plan_entry(int variant)
 {
     return {PL::N, variant, mixed_plan_kernel<PL, false>, mixed_plan_kernel<PL, true>, PL::WG, PL::FPW,
-            plan_lds_bytes<PL>(false), plan_lds_bytes<PL>(true)};
+            plan_lds_bytes<PL>(false), plan_lds_bytes<PL>(true), 1};
+}
+template <int P, class PL>
+constexpr PlanEntry split_entry(int variant)
+{
+    return {P * PL::N, variant, mixed_split_kernel<PL, P, false>, mixed_split_kernel<PL, P, true>, PL::WG, 1,
+            PL::LDS_BYTES, PL::LDS_BYTES, P};
 }
 template <int R, int G = 1>
 using P = MPass<R, G>;
@@ -388,11 +524,12 @@ using P = MPass<R, G>;
 template <class PL>
 constexpr PlanEntry plan_candidate(int variant)
 {
-    return {PL::N, variant, mixed_plan_kernel<PL, false>, nullptr, PL::WG, PL::FPW, plan_lds_bytes<PL>(false), 0};
+    return {PL::N, variant, mixed_plan_kernel<PL, false>, nullptr, PL::WG, PL::FPW, plan_lds_bytes<PL>(false), 0, 1};
 }
 #endif
 const PlanEntry kPlans[] = {
 #include "mixed_plans.inc"
+#include "mixed_plans_split.inc"
 #ifdef RPF_TUNING
 #include "mixed_plans_tuning.inc"
 #endif
@@ -470,6 +607,7 @@ hipError_t plan_mixed(int N, int variant, bool windowed, int device, LaunchInfo*
     hipDeviceProp_t prop;
     if ((err = hipGetDeviceProperties(&prop, device)) != hipSuccess) return err;
     li->grid = std::max(per_cu, 1) * prop.multiProcessorCount;
+    if (pe) li->grid -= li->grid % (pe->split > 1 ? 8 * pe->split : 1);        // (split form: see its XCD mapping)
     li->block = wg;
     li->fpw = pe ? pe->fpw : kMixedWG / threads_per_frame(N);
     li->lds_bytes = lds;
@@ -478,13 +616,18 @@ hipError_t plan_mixed(int N, int variant, bool windowed, int device, LaunchInfo*
 
 // d_twN: master twiddles W_N^k (make_twiddles); one partial spectrum of N doubles per workgroup.
 hipError_t launch_mixed(int N, int variant, const uint8_t* d_stream, long nframes, const cf* d_twN, const float* d_window,
-                        double* d_partial, int grid, hipStream_t stream, LaunchInfo* li)
+                        double* d_partial, int max_grid, hipStream_t stream, LaunchInfo* li)
 {
-    if (!mixed_supported(N, variant) || grid < 1 || nframes < 1) return hipErrorInvalidValue;
-    int wg = kMixedWG, fpw = 0, lds = 0;
+    if (!mixed_supported(N, variant) || max_grid < 1 || nframes < 1) return hipErrorInvalidValue;
+    int wg = kMixedWG, fpw = 0, lds = 0, grid = 0;
     if (const PlanEntry* pe = find_plan(N, variant)) {
         wg = pe->wg, fpw = pe->fpw, lds = d_window ? pe->lds_windowed : pe->lds;
         if (d_window && !pe->windowed) return hipErrorInvalidValue;      // (a tuning-build candidate)
+        // no more workgroups than frames to share out (x the split factor: one workgroup per residue)
+        long groups = std::min<long>(max_grid / pe->split, (nframes + fpw - 1) / fpw);
+        if (pe->split > 1 && groups > 8) groups -= groups % 8;        // whole rounds of the 8 XCDs
+        if (groups < 1) return hipErrorInvalidValue;
+        grid = static_cast<int>(groups) * pe->split;
         hipLaunchKernelGGL(d_window ? pe->windowed : pe->plain, dim3(grid), dim3(wg), lds, stream, d_stream, nframes, d_twN,
                            d_window, d_partial);
     } else {
@@ -492,14 +635,17 @@ hipError_t launch_mixed(int N, int variant, const uint8_t* d_stream, long nframe
         if (!factorise(N, &plan)) return hipErrorInvalidValue;
         const int tpf = threads_per_frame(N);
         fpw = kMixedWG / tpf, lds = lds_bytes(N);
+        grid = static_cast<int>(std::min<long>(max_grid, (nframes + fpw - 1) / fpw));
         hipLaunchKernelGGL(mixed_kernel, dim3(grid), dim3(kMixedWG), lds, stream, d_stream, nframes, N, tpf, plan, d_twN,
-                               d_window, d_partial);
+                           d_window, d_partial);
     }
     if (li) {
+        const PlanEntry* pe = find_plan(N, variant);
         li->grid = grid;
         li->block = wg;
         li->fpw = fpw;
         li->lds_bytes = lds;
+        li->slots = pe ? grid / pe->split : grid;
     }
     return hipGetLastError();
 }

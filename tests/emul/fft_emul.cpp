@@ -232,6 +232,67 @@ int run_mixed(const float* window, const uint8_t* stream, long nframes, double* 
     return 0;
 }
 
+// The split form (N = P M, workgroup p computes X[p + P k] with the M-point plan): pass 0 through
+// mix_unpack_split / mix_butterfly_split, the later passes as above.
+template <class PL, int P>
+int run_mixed_split(const float* window, const uint8_t* stream, long nframes, double* pwr)
+{
+    constexpr int M = PL::N, N = P * M, R0 = PL::R(0), G0 = PL::G(0);
+    std::vector<cf> twN(N);
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (int k = 0; k < N; ++k) {
+        long double a = two_pi * k / N;
+        twN[k] = {(float)cosl(a), (float)(-sinl(a))};
+    }
+    std::vector<cf> twM(M);
+    for (int k = 0; k < M; ++k) twM[k] = twN[(size_t)P * k];
+    for (int p = 0; p < P; ++p) {
+        cf wp[P], mid[R0];
+        for (int j = 0; j < P; ++j) wp[j] = twN[((long)j * p * M) % N];
+        for (int n1 = 0; n1 < R0; ++n1) mid[n1] = twN[((long)n1 * PL::S(0) * p) % N];
+        std::vector<std::vector<cf>> tws(PL::TPFMAX, std::vector<cf>(PL::NTW + 1));
+        for (int t = 0; t < PL::TPFMAX; ++t) mixed_load_tw<PL, 0>(t, twM, tws[t].data());
+        std::vector<std::vector<double>> acc(PL::TPFMAX, std::vector<double>(PL::PPTL, 0.0));
+        std::vector<cf> slab(PL::LDS_CPX);
+        for (long f = 0; f < nframes; ++f) {
+            const uint8_t* frame = stream + (size_t)f * 2 * N;
+            for (int t = 0; t < PL::TPF(0); ++t) {
+                cf v[PL::PPT0];
+                float sgn[G0];
+                for (int g = 0; g < G0; ++g) sgn[g] = ((t + g * PL::TPF(0)) & 1) ? -1.0f : 1.0f;
+                for (int j = 0; j < P; ++j) {
+                    uint32_t raw[PL::PPT0];
+                    for (int i = 0; i < PL::PPT0; ++i) {
+                        const int n = rpf::mix_sample_index<PL>(t, i / R0, i % R0) + j * M;
+                        raw[i] = frame[2 * n] | (uint32_t)frame[2 * n + 1] << 8;
+                    }
+                    const float* w = window ? window + j * M + t : nullptr;
+                    if (j == 0) {
+                        if (window) rpf::mix_split_accumulate<PL, true, true>(raw, sgn, w, wp[j], v);
+                        else rpf::mix_split_accumulate<PL, false, true>(raw, sgn, w, wp[j], v);
+                    } else {
+                        if (window) rpf::mix_split_accumulate<PL, true, false>(raw, sgn, w, wp[j], v);
+                        else rpf::mix_split_accumulate<PL, false, false>(raw, sgn, w, wp[j], v);
+                    }
+                }
+                rpf::mix_split_mid<PL>(v, mid);
+                for (int g = 0; g < G0; ++g) {
+                    const int ntail = t + g * PL::TPF(0);
+                    cf tw0[R0];
+                    for (int k = 0; k < R0; ++k) tw0[k] = twN[((long)ntail * (p + P * k)) % N];
+                    rpf::mix_butterfly_split<PL>(v + g * R0, tw0);
+                    rpf::mix_store<PL, 0>(rpf::mix_slot_base<PL, 0>(t, g), v + g * R0, slab.data());
+                }
+            }
+            mixed_passes<PL, 1>(tws, slab, frame, window, acc);
+        }
+        for (int t = 0; t < PL::TPF(PL::F - 1); ++t)
+            for (int g = 0; g < PL::G(PL::F - 1); ++g)
+                for (int k = 0; k < PL::RLAST; ++k) pwr[p + P * rpf::mix_bin<PL>(t, g, k)] = acc[t][g * PL::RLAST + k];
+    }
+    return 0;
+}
+
 }  // namespace
 
 using rpf::MixPlan;
@@ -252,13 +313,17 @@ extern "C" int rpf_emul_mixed(int plan, const float* window, const uint8_t* stre
         case 10: return run_mixed<MixPlan<700, 1, 0, MPass<7, 2>, MPass<10>, MPass<10>>>(window, stream, nframes, pwr);
         case 11: return run_mixed<MixPlan<2860, 1, 0, MPass<13>, MPass<11>, MPass<20>>>(window, stream, nframes, pwr);
         case 12: return run_mixed<MixPlan<782, 1, 0, MPass<17>, MPass<23>, MPass<2, 17>>>(window, stream, nframes, pwr);
+        case 13: return run_mixed_split<MixPlan<500, 1, 0, MPass<10>, MPass<10>, MPass<5, 2>>, 2>(window, stream, nframes, pwr);
+        case 14: return run_mixed_split<MixPlan<1000, 1, 0, MPass<10>, MPass<10>, MPass<10>>, 5>(window, stream, nframes, pwr);
+        case 15: return run_mixed_split<MixPlan<600, 1, 0, MPass<25>, MPass<24>>, 3>(window, stream, nframes, pwr);
+        case 16: return run_mixed_split<MixPlan<96, 1, 0, MPass<2, 3>, MPass<3, 2>, MPass<4>, MPass<4>>, 4>(window, stream, nframes, pwr);
     }
     return -1;
 }
 extern "C" int rpf_emul_mixed_n(int plan)
 {
-    const int n[] = {100, 500, 500, 1000, 1200, 300, 3600, 1080, 6000, 96, 700, 2860, 782};
-    return plan >= 0 && plan < 13 ? n[plan] : -1;
+    const int n[] = {100, 500, 500, 1000, 1200, 300, 3600, 1080, 6000, 96, 700, 2860, 782, 1000, 5000, 1800, 384};
+    return plan >= 0 && plan < 17 ? n[plan] : -1;
 }
 
 // v[k] <- sum_n v[n] W_R^{nk} through dft_small.h (interleaved re, im)

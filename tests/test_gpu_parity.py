@@ -151,6 +151,32 @@ def test_mixed_radix_sizes_match_oracle_and_bluestein(N, torch_dev):
         assert max_rel(got, other) < PARITY
 
 
+@pytest.mark.parametrize("N", [20000, 24000, 25000, 30000, 32768, 36000, 40000, 45000, 50000, 64000])
+def test_split_mixed_radix_sizes_match_oracle(N, torch_dev):
+    """N = P x M (P = 2 ... 5, M <= 16384 one of the planned lengths): the split form of the mixed-radix kernel
+    (one workgroup per residue of the spectrum, rpf_mixed.hip) against the float32 oracle, float64 truth and the
+    kernels it replaces by default (large Bluestein; the four-step pair for 32768); frame counts that leave some
+    groups of workgroups idle or the grid off a multiple of 8 P (the other workgroup -> residue mapping)."""
+    R = 11
+    stream = rpf.synth.uniform_iq(77 + N % 101, N * R + N // 2)
+    for windowed in (False, True):
+        w = rpf.synth.hann_window(N) + np.float32(0.25) if windowed else None
+        with rpf.Datastore(rpf.Params(N=N, window=windowed, repeats=R, buf_length=1 << 20), w) as ds:
+            got, n = run_device(ds, stream, R, torch_dev)
+            few, nfew = run_device(ds, stream, 3, torch_dev)
+            host, done = ds.accumulate(stream, R)          # 1 MB buffers: frames straddle them
+        with rpf.Datastore(rpf.Params(N=N, window=windowed, repeats=R), w,
+                           flags=rpf._lib.FLAG_NO_MIXED_RADIX) as other_ds:
+            other, _ = run_device(other_ds, stream, R, torch_dev)
+        assert n == done == R and nfew == 3
+        assert max_rel(host, got) < 1e-13
+        o32, _ = oracle_accumulate(N, stream, R, w, 32)
+        assert max_rel(got, o32) < PARITY
+        assert max_rel(got, truth_f64(N, stream, R, w)) < VS_TRUTH * 1.5
+        assert max_rel(got, other) < PARITY
+        assert max_rel(few, truth_f64(N, stream, 3, w)) < 2 * PARITY      # three frames: little averaging
+
+
 @pytest.mark.parametrize("N", [16384, 32768, 65536, 131072, 262144])
 def test_four_step_sizes_match_oracle(N, torch_dev):
     """Powers of two beyond one workgroup's LDS (rpf_fourstep.hip; 262144 is config
