@@ -88,3 +88,47 @@ def test_product_does_not_link_the_oracle():
     assert "rpf_oracle" not in out and "rpf_emul" not in out
     syms = subprocess.run(["nm", "-D", _lib.lib_path()], capture_output=True, text=True).stdout
     assert "rpf_oracle" not in syms
+
+
+def test_shipped_mixed_radix_plans_are_well_formed():
+    """mixed_plans.inc / mixed_plans_split.inc (what tools/pick_mixed_plans.py and a human wrote): radices multiply to
+    the length, butterflies per thread divide it, the workgroup and its LDS fit the hardware, no size twice, and the
+    engine reports every planned size as supported."""
+    import re
+    lib = rpf.load()
+    seen = set()
+    for name in ("mixed_plans.inc", "mixed_plans_split.inc"):
+        text = open(os.path.join(ROOT, "rtl-power-fftw_amd", "csrc", name)).read().split("#ifdef RPF_TUNING")[0]
+        macros = dict(re.findall(r"#define (RPF_M\d+) (MixPlan<.*>)", text))
+        for split, plan, variant in re.findall(r"(?:plan|split)_entry<(?:(\d+), )?(RPF_M\d+|MixPlan<[^()]*>)>\((\d+)\)", text):
+            plan = macros.get(plan, plan)
+            m = re.match(r"MixPlan<(\d+), (\d+), (\d+), (.*)>$", plan)
+            assert m, plan
+            length, fpw, tw = int(m.group(1)), int(m.group(2)), int(m.group(3))
+            passes = [(int(r), int(g or 1)) for r, g in re.findall(r"P<(\d+)(?:, (\d+))?>", m.group(4))]
+            prod = 1
+            for r, g in passes:
+                prod *= r
+                assert 2 <= r <= 25 and length % (r * g) == 0, plan
+            assert prod == length and len(passes) >= 2 and int(variant) == 0, plan
+            tpf = max(length // (r * g) for r, g in passes)
+            assert fpw * tpf <= 1024 and tw in (0, 1, 2), plan
+            rlast = passes[-1][0]
+            cpx = length + length // rlast if rlast % 2 == 0 else length
+            table = 0
+            if tw == 1:
+                table = sum(g * (r - 1) * (length // (r * g)) for r, g in passes[:-1])
+            elif tw == 2:
+                s = length
+                for i, (r, g) in enumerate(passes[:-1]):
+                    s //= r
+                    if i >= 1:
+                        table += (r - 1) * s
+            assert (fpw * cpx + table) * 8 <= 160 * 1024, plan
+            n = length * int(split or 1)
+            if split:
+                assert fpw == 1 and tw != 1 and length % 2 == 0 and 2 <= int(split) <= 5, plan
+            assert n not in seen, n
+            seen.add(n)
+            assert lib.rpf_supported_n(n) == 1, n
+    assert len(seen) > 150 and {500, 1000, 7000, 10000, 16384, 20000, 32768, 50000} <= seen
