@@ -1,20 +1,22 @@
 // rpf_mixed.hip -- KM: LDS-resident mixed-radix kernels for the "round" sizes people actually
-// type: even N <= 16384 with small prime factors (2, 3, 5; 7 ... 23 for multiples of 100) that are not powers of
-// two -- and 16384 itself
-// (500 -- the man page's own example, doc/rtl_power_fftw.1.md:182 --, 1000, 1200, 2000, 3000,
-// 5000, 10000, ...).  Bluestein (KB) serves such sizes with two power-of-two transforms of 2-4 N
-// points each; a transform of the length itself costs a fifth of that.
+// type (500 -- the man page's own example, doc/rtl_power_fftw.1.md:182 --, 1000, 1200, 2000, 3000,
+// 5000, 7000, 10000, 15000, 20000, 50000 ...) and for 16384 and 32768.  Bluestein serves such sizes
+// with two power-of-two transforms of 2-4 N points each; a transform of the length itself costs a
+// fifth of that.
 //
-// Two kernels:
+// Three kernels:
 //  * mixed_plan_kernel (mixed_core.h, dft_small.h): K1's scheme -- in place by element name
-//    through one padded LDS slab, composite radices up to 25 (two to four passes), twiddles and the
-//    f64 accumulators in registers for the whole launch -- compiled for the sizes of
-//    mixed_plans.inc with the plan (radices, butterflies per thread, frame slots per workgroup,
-//    twiddle placement) that measured fastest on the GPU (tools/gen_mixed_plans.py,
-//    tools/pick_mixed_plans.py, profiles/r02_mixed_plan_search.txt).  500 ... 1060 Gsample/s.
-//  * mixed_kernel: any other such size up to 5120, runtime plan: Stockham autosort, decimation in
-//    frequency, one radix (5, 4, 3, 2) per pass, natural order in and out, two LDS buffers per
-//    frame slot:
+//    through one padded LDS slab, radices 2 ... 25 (two to four passes), twiddles and the f64
+//    accumulators in registers for the whole launch -- compiled for the 145 sizes of
+//    mixed_plans.inc (N <= 16384) with the plan (radices, butterflies per thread, frame slots per
+//    workgroup, twiddle placement) that measured fastest on the GPU (tools/gen_mixed_plans.py,
+//    tools/pick_mixed_plans.py, profiles/r02_mixed_plan_search.txt).  0.25 ... 1.06 Tsample/s.
+//  * mixed_split_kernel: N = P M, P = 2 ... 5, M one of those lengths (mixed_plans_split.inc:
+//    20000 ... 64000, 32768): workgroup b computes the residue p of the spectrum,
+//    X[p + P k] = FFT_M(x'_p)[k], so only raw bytes cross workgroups.  0.16 ... 0.46 Tsample/s.
+//  * mixed_kernel: any other even N <= 5120 with prime factors 2, 3, 5, runtime plan: Stockham
+//    autosort, decimation in frequency, one radix (5, 4, 3, 2) per pass, natural order in and
+//    out, two LDS buffers per frame slot:
 //
 //   pass with sub-length n = N / s, n1 = n / r, butterfly (p < n1, q < s):
 //       y[q + s (r p + j)] = W_n^{p j} * sum_k x[q + s (p + k n1)] W_r^{j k},     W_n^{p j} = W_N^{p j s}
@@ -23,8 +25,9 @@
 //    threads of a frame) and applies (v - 127) (-1)^n [window] exactly like K1; the last pass
 //    leaves |X|^2 in double accumulators that live in LDS for the whole launch (one owner thread
 //    per bin: plain read-modify-write).  TPF threads per frame (a power of two, about N/4),
-//    WG / TPF frames side by side in a 256-thread workgroup.  100 ... 300 Gsample/s.
-// HBM traffic of both = the 2N input bytes per frame; bound by VALU + LDS like K1.
+//    WG / TPF frames side by side in a 256-thread workgroup.  0.1 ... 0.3 Tsample/s.
+// HBM traffic of all three = the input bytes (2N per frame; P times that from L2 in the split
+// form); bound by VALU + LDS like K1 (the split form also by its 2-byte load instructions).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
