@@ -320,6 +320,34 @@ extern "C" int rpf_emul_mixed(int plan, const float* window, const uint8_t* stre
     }
     return -1;
 }
+// every plan the product ships (the kernel tables themselves, with the emulator's runners in place of the kernels)
+struct ShippedPlan {
+    int N;
+    int (*run)(const float*, const uint8_t*, long, double*);
+};
+template <class PL>
+constexpr ShippedPlan plan_entry(int)
+{
+    return {PL::N, &run_mixed<PL>};
+}
+template <int SPLIT, class PL>
+constexpr ShippedPlan split_entry(int)
+{
+    return {SPLIT * PL::N, &run_mixed_split<PL, SPLIT>};
+}
+template <int R, int G = 1>
+using P = MPass<R, G>;
+const ShippedPlan kShipped[] = {
+#include "../../rtl-power-fftw_amd/csrc/mixed_plans.inc"
+#include "../../rtl-power-fftw_amd/csrc/mixed_plans_split.inc"
+};
+extern "C" int rpf_emul_shipped_count() { return (int)(sizeof kShipped / sizeof kShipped[0]); }
+extern "C" int rpf_emul_shipped_n(int i) { return kShipped[i].N; }
+extern "C" int rpf_emul_shipped(int i, const float* window, const uint8_t* stream, long nframes, double* pwr)
+{
+    return kShipped[i].run(window, stream, nframes, pwr);
+}
+
 extern "C" int rpf_emul_mixed_n(int plan)
 {
     const int n[] = {100, 500, 500, 1000, 1200, 300, 3600, 1080, 6000, 96, 700, 2860, 782, 1000, 5000, 1800, 384};

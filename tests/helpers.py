@@ -69,6 +69,7 @@ def emul_lib():
         lib.rpf_emul_bluestein.argtypes = [ctypes.c_int, fp, u8p, ctypes.c_long, dp]
         lib.rpf_emul_mixed.argtypes = [ctypes.c_int, fp, u8p, ctypes.c_long, dp]
         lib.rpf_emul_small_dft.argtypes = [ctypes.c_int, fp]
+        lib.rpf_emul_shipped.argtypes = [ctypes.c_int, fp, u8p, ctypes.c_long, dp]
         _emul = lib
     return _emul
 
@@ -85,6 +86,26 @@ def emul_mixed(plan, stream, repeats, window=None):
         w = window.ctypes.data_as(fp)
     pwr = np.zeros(N)
     assert lib.rpf_emul_mixed(plan, w, stream.ctypes.data_as(u8p), repeats, pwr.ctypes.data_as(dp)) == 0
+    return pwr
+
+
+def emul_shipped_sizes():
+    """The sizes of mixed_plans.inc + mixed_plans_split.inc, in table order."""
+    lib = emul_lib()
+    return [lib.rpf_emul_shipped_n(i) for i in range(lib.rpf_emul_shipped_count())]
+
+
+def emul_shipped(index, stream, repeats, window=None):
+    """Entry `index` of the shipped plan tables run through mixed_core.h thread by thread."""
+    lib = emul_lib()
+    N = lib.rpf_emul_shipped_n(index)
+    stream = np.ascontiguousarray(stream, dtype=np.uint8)
+    w = None
+    if window is not None:
+        window = np.ascontiguousarray(window, dtype=np.float32)
+        w = window.ctypes.data_as(fp)
+    pwr = np.full(N, np.nan)
+    assert lib.rpf_emul_shipped(index, w, stream.ctypes.data_as(u8p), repeats, pwr.ctypes.data_as(dp)) == 0
     return pwr
 
 

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 import rtl_power_fftw_amd as rpf
-from helpers import (emul_accumulate, emul_bluestein, emul_mixed, emul_mixed_n, emul_small_dft, max_err_over_mean, max_rel,
+from helpers import (emul_accumulate, emul_bluestein, emul_mixed, emul_mixed_n, emul_shipped, emul_shipped_sizes, emul_small_dft,
+                     max_err_over_mean, max_rel,
                      oracle_accumulate, truth_f64)
 
 CASES = [(64, 8), (128, 8), (256, 8), (512, 8), (1024, 8), (4096, 8), (128, 16), (256, 16), (512, 16),
@@ -97,3 +98,20 @@ def test_emulated_mixed_plan_bin_placement():
     got = emul_mixed(plan, frame, 1)
     assert int(np.argmax(got)) == (k0 + N // 2) % N
     assert np.sort(got)[-2] < 1e-3 * got.max()
+
+
+def test_every_shipped_mixed_radix_plan_on_the_emulator():
+    """All plans of mixed_plans.inc and mixed_plans_split.inc -- the tables the library is compiled from, with the
+    emulator's thread-by-thread runners in place of the kernels: element names, slots, twiddle indices, bin
+    placement (every bin written exactly once) and the split form's residues, against float64 truth; windowed for
+    every third size."""
+    sizes = emul_shipped_sizes()
+    assert len(sizes) > 150 and len(set(sizes)) == len(sizes)
+    for i, N in enumerate(sizes):
+        R = 2
+        stream = rpf.synth.uniform_iq(1000 + N, N * R)
+        w = rpf.synth.hann_window(N) + np.float32(0.25) if i % 3 == 0 else None
+        got = emul_shipped(i, stream, R, w)
+        assert np.all(np.isfinite(got)), N
+        # two frames: little averaging, so against max(bin, mean bin) like the other small cases
+        assert max_err_over_mean(got, truth_f64(N, stream, R, w)) < 2e-6, N
