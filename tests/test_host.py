@@ -425,3 +425,27 @@ def test_cli_scan_spread_over_several_engines(host, tmp_path):
     assert m1.returncode == 0 and m2.returncode == 0, m1.stderr + m2.stderr
     assert (tmp_path / "m1.bin").read_bytes() == (tmp_path / "m2.bin").read_bytes()
     assert (tmp_path / "m1.met").read_text().split("\n")[:5] == (tmp_path / "m2.met").read_text().split("\n")[:5]
+
+
+def test_mixed_plan_generator_emits_valid_candidates():
+    """tools/gen_mixed_plans.py (the candidate plans the GPU search times): every candidate of every size multiplies
+    to its length, stays within 1024 threads and 160 KB of LDS, and the numbering the picker relies on is stable."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_mixed_plans", os.path.join(ROOT, "tools", "gen_mixed_plans.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    total = 0
+    for n in gen.SIZES[::7] + [500, 7000, 10000]:
+        cands = gen.candidates(n)
+        assert cands == gen.candidates(n)
+        for cost, rad, gs, fpw, tw in cands:
+            prod = 1
+            for r, g in zip(rad, gs):
+                prod *= r
+                assert r in gen.RADICES and n % (r * g) == 0 and r * g <= 32
+            assert prod == n and tw in (0, 1, 2)
+            assert fpw * max(n // (r * g) for r, g in zip(rad, gs)) <= 1024
+            assert gen.lds_bytes(n, rad, gs, fpw, tw) <= 163840
+            assert "MixPlan<%d, %d, %d," % (n, fpw, tw) in gen.entry(n, rad, gs, fpw, tw, 1)
+        total += len(cands)
+    assert total > 100
