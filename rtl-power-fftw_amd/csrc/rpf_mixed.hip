@@ -27,7 +27,7 @@
 //    per bin: plain read-modify-write).  TPF threads per frame (a power of two, about N/4),
 //    WG / TPF frames side by side in a 256-thread workgroup.  0.1 ... 0.3 Tsample/s.
 // HBM traffic of all three = the input bytes (2N per frame; P times that from L2 in the split
-// form); bound by VALU + LDS like K1 (the split form also by its 2-byte load instructions).
+// form); bound by VALU + LDS like K1.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
