@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Candidate plans for the planned mixed-radix kernel (rpf_mixed.hip / mixed_core.h).
 
+  python tools/gen_mixed_plans.py splitsearch 20000 50000 ... >> rtl-power-fftw_amd/csrc/mixed_plans_tuning.inc
+      candidates of the split form (N = P x M) for the listed sizes, variants 11, 12, ...; `splitcases` prints the
+      N:variant arguments for tools/gpu_sweep.py.  (mixed_plans_split.inc itself is hand-listed.)
   python tools/gen_mixed_plans.py search  > rtl-power-fftw_amd/csrc/mixed_plans_tuning.inc
       every candidate (radices, butterflies per thread, frame slots per workgroup, twiddle
       placement) of every size in SIZES as a variant of the tuning build; tools/gpu_sweep.py
@@ -173,6 +176,34 @@ EXTRA = {8192: [((16, 8, 8, 8), (2, 4, 4, 4), 1, 2), ((16, 8, 8, 8), (2, 4, 4, 4
                ((25, 6), (1, 5), 40, 0)]}
 
 
+def split_candidates(n):
+    """The split form (mixed_split_kernel): n = P x M, P = 2 ... 5, M <= 16384 even -- every single-slot candidate of M
+    (search2 rules) with its later passes' twiddles in LDS tables (mode 2, what the split kernel's registers allow)."""
+    global TW_MODES, MAXPPT
+    saved = TW_MODES, MAXPPT
+    TW_MODES, MAXPPT = (0, 1, 2), 32
+    out, seen = [], set()
+    try:
+        for p in (2, 3, 4, 5):
+            m = n // p
+            if n % p or m % 2 or m > 16384:
+                continue
+            for cost, rad, gs, fpw, tw in candidates(m):
+                key = (p, rad, gs)
+                if fpw != 1 or tw == 1 or len(rad) < 3 or key in seen:
+                    continue
+                seen.add(key)
+                out.append((p, m, rad, gs))
+    finally:
+        TW_MODES, MAXPPT = saved
+    return out
+
+
+def split_entry(p, m, rad, gs, variant):
+    passes = ", ".join("P<%d%s>" % (r, (", %d" % g) if g != 1 else "") for r, g in zip(rad, gs))
+    return "    split_entry<%d, MixPlan<%d, 1, 2, %s>>(%d)," % (p, m, passes, variant)
+
+
 def variant_base(n):
     """K1's own tuning variants use the low numbers for the powers of two."""
     return 100 if n & (n - 1) == 0 else 0
@@ -191,6 +222,20 @@ def main():
         TW_MODES = (0, 1, 2)
         MAXPPT = 32
         mode = mode[:-1]
+    if mode == "splitsearch":      # candidates of the split form as variants 11, 12, ... of the tuning build
+        print("// generated by tools/gen_mixed_plans.py splitsearch -- tuning build only")
+        for n in sizes:
+            for v, (p, m, rad, gs) in enumerate(split_candidates(n), start=11 + variant_base(n)):
+                print(split_entry(p, m, rad, gs, v))
+        return
+    if mode == "splitcases":
+        print(" ".join("%d:%d" % (n, v + variant_base(n)) for n in sizes for v in range(11, 11 + len(split_candidates(n)))))
+        return
+    if mode == "splitlist":
+        for n in sizes:
+            for v, (p, m, rad, gs) in enumerate(split_candidates(n), start=11 + variant_base(n)):
+                print(n, v, "P", p, "M", m, rad, gs)
+        return
     if mode == "search":
         print("// generated by tools/gen_mixed_plans.py search -- tuning build only")
         for n in sizes:
