@@ -62,7 +62,7 @@ typedef struct rpf_config {
  * two-kernel path so far, hence opt-in; the engine falls back by itself where the
  * kernel's teams cannot assemble. */
 #define RPF_FLAG_FOURSTEP_FUSED 2u
-/* Sizes served by the LDS mixed-radix kernels (500, 1000, 3000 ... 64000; 16384, 32768): use the
+/* Sizes served by the LDS mixed-radix kernels (500, 1000, 3000 ... 80000; 16384, 32768): use the
  * kernel they would get without them -- Bluestein, resp. the four-step pair for 16384 and 32768
  * (A/B measurement; all are exact to the float32 bar). */
 #define RPF_FLAG_NO_MIXED_RADIX 4u

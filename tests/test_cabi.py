@@ -99,8 +99,8 @@ def test_shipped_mixed_radix_plans_are_well_formed():
     seen = set()
     for name in ("mixed_plans.inc", "mixed_plans_split.inc"):
         text = open(os.path.join(ROOT, "rtl-power-fftw_amd", "csrc", name)).read().split("#ifdef RPF_TUNING")[0]
-        macros = dict(re.findall(r"#define (RPF_M\d+) (MixPlan<.*>)", text))
-        for split, plan, variant in re.findall(r"(?:plan|split)_entry<(?:(\d+), )?(RPF_M\d+|MixPlan<[^()]*>)>\((\d+)\)", text):
+        macros = dict(re.findall(r"#define (RPF_M\w+) (MixPlan<.*>)", text))
+        for split, plan, variant in re.findall(r"(?:plan|split)_entry<(?:(\d+), )?(RPF_M\w+|MixPlan<[^()]*>)>\((\d+)\)", text):
             plan = macros.get(plan, plan)
             m = re.match(r"MixPlan<(\d+), (\d+), (\d+), (.*)>$", plan)
             assert m, plan

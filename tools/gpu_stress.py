@@ -28,7 +28,7 @@ def five_smooth(n):
 SMOOTH = [n for n in range(6, 10001, 2) if n & (n - 1) and five_smooth(n)] + \
          [700, 1100, 1300, 1400, 1700, 1900, 2100, 2300, 3500, 4900, 6500, 7000, 7700, 9500, 9900,    # prime radices 7 ... 23
           11000, 12000, 12500, 12800, 13000, 14400, 15000, 15360, 16000, 16384,                # 32 points per thread
-          20000, 24000, 25000, 30000, 32000, 32768, 36000, 40000, 45000, 48000, 50000, 60000, 64000]   # split form
+          20000, 24000, 25000, 30000, 32000, 32768, 36000, 40000, 45000, 48000, 50000, 60000, 64000, 75000, 80000]   # split form
 t0 = time.time()
 ncase = 0
 worst = 0.0
