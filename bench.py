@@ -11,7 +11,8 @@ Workloads (--workload, default "auto" = C2 on one GPU, C5 on sever
   C4  one step = one acquisition, N=262144 bins x 1000 repeats (four-step kernels)
   C5  one step = one 8-hop scan, N=4096 x 5000 repeats per hop, hop h = seed 50+h.
       STRONG scaling: the 8 x 5000 frames of a scan are dealt hop-major to the ranks
-      (sharding.shard_hops), every rank runs the fused kernel on its frame ranges and the
+      (sharding.shard_hops), every rank runs ONE launch of the fused kernel over its hops' frame
+      ranges (rpf_accumulate_device_hops: accumulators handed over and zeroed at hop boundaries) and the
       per-bin accumulators meet in ONE asynchronous RCCL reduce of 8 x 4096 doubles per
       scan, overlapped with the next scan's kernels.  Rank 0 checks the reduced spectra
       against the committed float64 fixtures (tests/golden/c5_hop*.npz) before printing.
@@ -277,6 +278,8 @@ def main():
     # what this rank processes per step: list of (hop, first_frame, frames)
     if strong:
         mine = rpf.sharding.shard_hops(hops, R, args.shard_as or world, rank)
+        # hop-major contiguous shards: a rank's hops are consecutive rows of the scan's block
+        assert [m[0] for m in mine] == list(range(mine[0][0], mine[0][0] + len(mine)))
     else:
         mine = [(0, 0, R)]
     # the streams, generated on the device (bit-identical to synth.noise_tones_iq)
@@ -313,14 +316,25 @@ def main():
         if new_block:
             ring.begin(blk)
         streams = bufs[i % nb]
-        for k, (hop, first, count) in enumerate(mine):
-            out_row = d_pwr[blk][hop if strong else row]
-            if ev is not None and k == 0:
+        if strong:
+            # the rank's hops of the scan in ONE persistent launch + ONE reduce (rpf_accumulate_device_hops'
+            # two halves, so that the events bracket the fused kernel alone)
+            if ev is not None:
                 ev[0].record()
-            ds.device_fused(streams[k].data_ptr(), 2 * N * count, count, s)
-            if ev is not None and k == 0:
+            ds.device_fused_hops([b.data_ptr() for b in streams], [2 * N * c for _, _, c in mine],
+                                 [c for _, _, c in mine], s)
+            if ev is not None:
                 ev[1].record()
-            ds.device_reduce(out_row.data_ptr(), s)
+            ds.device_reduce(d_pwr[blk][mine[0][0]].data_ptr(), s)
+        else:
+            for k, (hop, first, count) in enumerate(mine):
+                out_row = d_pwr[blk][row]
+                if ev is not None and k == 0:
+                    ev[0].record()
+                ds.device_fused(streams[k].data_ptr(), 2 * N * count, count, s)
+                if ev is not None and k == 0:
+                    ev[1].record()
+                ds.device_reduce(out_row.data_ptr(), s)
         if last_of_block:
             ring.submit(blk)
         return blk
@@ -405,8 +419,8 @@ def main():
             d_one = torch.zeros(hops, N, dtype=torch.float64, device=dev)
 
             def scan():
-                for h in range(hops):
-                    ds.accumulate_device(all_hops[h].data_ptr(), 2 * N * R, R, d_one[h].data_ptr(), s)
+                ds.accumulate_device_hops([a.data_ptr() for a in all_hops], [2 * N * R] * hops, [R] * hops,
+                                          d_one.data_ptr(), s)
             for _ in range(20):
                 scan()
             torch.cuda.synchronize()
@@ -427,8 +441,10 @@ def main():
         k1_all = [a.elapsed_time(b) for a, b in events]
         k1_ms = float(np.median(k1_all)) if events else None
         k1_mean_ms = float(np.mean(k1_all)) if events else None
-        frames_per_launch = mine[0][2]
-        alg_bytes = 2 * N * frames_per_launch + 8 * N + (4 * N if window is not None else 0)
+        # one launch of the dominant kernel: one acquisition (C2-C4), the rank's hops of the scan (C5)
+        frames_per_launch = sum(m[2] for m in mine) if strong else mine[0][2]
+        hops_per_launch = len(mine) if strong else 1
+        alg_bytes = 2 * N * frames_per_launch + hops_per_launch * 8 * N + (4 * N if window is not None else 0)
         info = ds.launch_info()
         roof = None
         if k1_ms:
@@ -452,6 +468,7 @@ def main():
                                        + str(traffic_note)) if traffic else None,
                     "kernel": kernel, "kernel_ms": k1_ms, "kernel_ms_mean": k1_mean_ms, "kernel_ms_samples": len(events),
                     "algorithmic_bytes_per_launch": alg_bytes, "frames_per_launch": frames_per_launch,
+                    "hops_per_launch": hops_per_launch,
                     "samples_per_s_kernel_only": N * frames_per_launch / (k1_ms * 1e-3),
                     # the contracted roofline is HBM read; what actually limits the kernel:
                     "limited_by": "fp32-valu + lds (see secondary): ~55 flop/B against a machine balance of ~20",

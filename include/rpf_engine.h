@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RPF_ABI_VERSION 1
+#define RPF_ABI_VERSION 2   /* 2: rpf_accumulate_device_hops, rpf_device_fused_hops */
 
 /* Return codes = ReturnValue of /root/reference/src/exceptions.h:25-34. */
 #define RPF_OK 0
@@ -139,10 +139,29 @@ int rpf_accumulate_device(rpf_engine* e, const void* d_stream, size_t nbytes, in
  * benchmark can bracket the dominant kernel alone with events on `hip_stream`:
  * _fused runs K1 (unpack+FFT+|X|^2) and leaves one partial spectrum per frame
  * slot in engine scratch; _reduce runs K3 over the scratch of the last _fused
- * call into d_pwr_out[N]. */
+ * call into d_pwr_out[N] (after rpf_device_fused_hops: all n_hops spectra, d_pwr_out[n_hops x N]). */
 int rpf_device_fused(rpf_engine* e, const void* d_stream, size_t nbytes, int64_t repeats,
                      void* hip_stream, int64_t* repeats_done);
 int rpf_device_reduce(rpf_engine* e, double* d_pwr_out, void* hip_stream);
+
+/* A whole scan in one call: n_hops device-resident acquisitions (the reference's scan is a loop of
+ * hops, /root/reference/src/rtl_power_fftw.cxx:133-174, each starting from a zeroed accumulator,
+ * acquisition.cxx:252-254).  Hop h = the first min(repeats[h], nbytes[h]/(2N)) frames of
+ * d_streams[h]; its spectrum goes to d_pwr_out[h*N .. h*N+N) (device doubles, overwritten; zeros
+ * for a hop without a whole frame).  For the sizes the LDS-resident kernel serves (powers of two
+ * 64 .. 8192) up to rpf_max_hops_per_launch() hops share ONE persistent kernel launch -- the
+ * workgroups walk the hops' frames as one sequence and hand over / zero their register
+ * accumulators at each hop boundary -- and ONE reduce launch, so a scan pays the per-launch
+ * fixed cost once instead of once per hop; other sizes run hop by hop.  Same stream, alignment
+ * and synchronisation rules as rpf_accumulate_device.  repeats_done: n_hops entries or NULL. */
+int rpf_accumulate_device_hops(rpf_engine* e, const void* const* d_streams, const size_t* nbytes,
+                               const int64_t* repeats, int n_hops, double* d_pwr_out /* n_hops x N */,
+                               void* hip_stream, int64_t* repeats_done);
+/* The fused-kernel half of it alone (n_hops <= rpf_max_hops_per_launch(), LDS-resident sizes
+ * only, else RPF_ERR_INVALID_ARGUMENT); rpf_device_reduce then writes all n_hops spectra. */
+int rpf_device_fused_hops(rpf_engine* e, const void* const* d_streams, const size_t* nbytes,
+                          const int64_t* repeats, int n_hops, void* hip_stream, int64_t* repeats_done);
+int rpf_max_hops_per_launch(void);
 
 /* Launch geometry of the last fused-kernel launch (for DESIGN/bench reporting):
  * workgroups, threads per workgroup, frames per workgroup, LDS bytes. */

@@ -71,6 +71,13 @@ _SYMBOLS = [
     ("rpf_device_fused", ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.c_int64, _P,
                                         ctypes.POINTER(ctypes.c_int64)]),
     ("rpf_device_reduce", ctypes.c_int, [_P, _P, _P]),
+    ("rpf_accumulate_device_hops", ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_size_t),
+                                                  ctypes.POINTER(ctypes.c_int64), ctypes.c_int, _P, _P,
+                                                  ctypes.POINTER(ctypes.c_int64)]),
+    ("rpf_device_fused_hops", ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_size_t),
+                                             ctypes.POINTER(ctypes.c_int64), ctypes.c_int, _P,
+                                             ctypes.POINTER(ctypes.c_int64)]),
+    ("rpf_max_hops_per_launch", ctypes.c_int, []),
     ("rpf_last_launch_info", ctypes.c_int, [_P] + [ctypes.POINTER(ctypes.c_int)] * 4),
 ]
 
@@ -117,7 +124,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.rpf_abi_version() != 1:
+    if lib.rpf_abi_version() != 2:
         raise RPFError("librpf_engine.so ABI mismatch", ReturnValue.HardwareError)
     _LIB = lib
     return lib

@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -108,6 +109,8 @@ struct rpf_engine {
     rpf::LaunchInfo plan;                 // resident grid for this N
     rpf::LaunchInfo last;                 // last launch
     int last_slots = 0;                   // partial spectra left by the last transform
+    rpf::SlotRanges last_ranges;          // ... and which of them belong to which hop (K1 hop launches)
+    int last_hops = 0;                    // hops of the last rpf_device_fused_hops (0: a single-acquisition transform)
 
     mutable std::string last_error;
 };
@@ -151,6 +154,30 @@ private:
             return fail(e, RPF_ERR_HARDWARE,                                             \
                         std::string(#call) + ": " + hipGetErrorString(err__));           \
     } while (0)
+
+// K1 over up to rpf::kMaxHops acquisitions in ONE launch (hop_partition.h): leaves the partial
+// spectra of hop h in the slots [slots->begin[h], slots->begin[h+1]) of e->d_partial.
+int launch_fused_hops(rpf_engine* e, const uint8_t* const* d_frames, const int64_t* nframes, int H,
+                      hipStream_t stream, rpf::SlotRanges* slots, int* nslots)
+{
+    rpf::HopArgs args;
+    bool interleave_single = false;
+#ifdef RPF_TUNING
+    interleave_single = H == 1 && std::getenv("RPF_TUNE_INTERLEAVE") != nullptr;     // A/B of the two iteration orders
+#endif
+    const int grid = rpf::partition_hops(nframes, H, e->plan.fpw, e->plan.grid, &args, slots, interleave_single);
+    if (grid < 0) return fail(e, RPF_ERR_INVALID_ARGUMENT, "too many frames for one launch");
+    bool dma = e->use_dma;
+    for (int h = 0; h < rpf::kMaxHops; ++h) {
+        args.stream[h] = h < H ? d_frames[h] : nullptr;
+        if (h < H && nframes[h] > 0 && (reinterpret_cast<uintptr_t>(d_frames[h]) % 16) != 0) dma = false;
+    }
+    *nslots = slots->begin[H];
+    if (grid == 0) return RPF_OK;           // no whole frame anywhere: every slot range is empty
+    HIP_TRY(e, rpf::launch_fft_accum_hops(e->N, e->variant, e->has_window, dma, args, e->d_twiddles, e->d_window,
+                                          e->d_partial, grid, stream, &e->last));
+    return RPF_OK;
+}
 
 // Enqueue K1 (or the four-step pair K2a/K2b) for `nframes` frames starting at
 // d_frames; leaves *nslots partial spectra in e->d_partial.
@@ -198,14 +225,23 @@ int launch_transform(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, hi
         *nslots = e->last.slots ? e->last.slots : e->last.grid;
         return RPF_OK;
     }
-    const int64_t wanted = (nframes + e->plan.fpw - 1) / e->plan.fpw;
-    const int grid = static_cast<int>(std::min<int64_t>(e->plan.grid, wanted));
     if (e->bluestein) {
+        const int64_t wanted = (nframes + e->plan.fpw - 1) / e->plan.fpw;
+        const int grid = static_cast<int>(std::min<int64_t>(e->plan.grid, wanted));
         HIP_TRY(e, rpf::launch_bluestein(e->N, d_frames, nframes, e->d_twiddles, e->d_chirp, e->d_bhat,
                                          e->d_partial, grid, stream, &e->last));
         *nslots = grid;
         return RPF_OK;
     }
+    // K1, one acquisition per launch
+#ifdef RPF_TUNING
+    if (std::getenv("RPF_TUNE_SCAN_KERNEL")) {      // A/B: the scan kernel on a scan of one hop
+        rpf::SlotRanges slots;
+        return launch_fused_hops(e, &d_frames, &nframes, 1, stream, &slots, nslots);
+    }
+#endif
+    const int64_t wanted = (nframes + e->plan.fpw - 1) / e->plan.fpw;
+    const int grid = static_cast<int>(std::min<int64_t>(e->plan.grid, wanted));
     const bool dma = e->use_dma && (addr % 16) == 0;
     HIP_TRY(e, rpf::launch_fft_accum(e->N, e->variant, e->has_window, dma, d_frames, nframes, e->d_twiddles,
                                      e->d_window, e->d_partial, grid, stream, &e->last));
@@ -222,6 +258,7 @@ int launch_frames(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, doubl
     int rc = launch_transform(e, d_frames, nframes, stream, &nslots);
     if (rc != RPF_OK) return rc;
     e->last_slots = nslots;
+    e->last_hops = 0;
     HIP_TRY(e, rpf::launch_reduce(e->d_partial, nslots, e->N, d_out, accumulate, stream,
                                   e->plan.partial_f32, e->bigblu ? static_cast<size_t>(e->blu_M) : 0));
     // a fused launch whose teams did not assemble must not leave something that looks like a spectrum
@@ -585,7 +622,7 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         rpf::LaunchInfo tmp;
         CREATE_TRY(rpf::plan_launch(e->N, e->variant, e->has_window, false, e->device, &tmp));
         e->plan.grid = std::min(e->plan.grid, tmp.grid);
-        partial_slots = e->plan.grid;
+        partial_slots = e->plan.grid + rpf::kMaxHops;    // a workgroup leaves one partial per hop it touches
     }
     CREATE_TRY(hipMalloc(&e->d_partial, sizeof(double) * partial_len * partial_slots));
     CREATE_TRY(hipMalloc(&e->d_pwr, sizeof(double) * e->N));
@@ -839,20 +876,122 @@ int rpf_device_fused(rpf_engine* e, const void* d_stream, size_t nbytes, int64_t
     int nslots = 0;
     int rc = launch_transform(e, static_cast<const uint8_t*>(d_stream), nframes,
                               static_cast<hipStream_t>(hip_stream), &nslots);
-    if (rc == RPF_OK) e->last_slots = nslots;
+    if (rc == RPF_OK) {
+        e->last_slots = nslots;
+        e->last_hops = 0;
+    }
     return rc;
 }
 
 int rpf_device_reduce(rpf_engine* e, double* d_pwr_out, void* hip_stream)
 {
     if (!e || !d_pwr_out) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_reduce: NULL argument");
-    if (e->last_slots < 1) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_reduce: nothing to reduce");
+    if (e->last_slots < 1 && e->last_hops < 1) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_reduce: nothing to reduce");
     DeviceScope on_device(e->device);
     HIP_TRY(e, on_device.status());
+    if (e->last_hops > 0) {
+        HIP_TRY(e, rpf::launch_reduce_hops(e->d_partial, e->last_ranges, e->last_hops, e->N, d_pwr_out,
+                                           /*accumulate=*/false, static_cast<hipStream_t>(hip_stream), e->plan.partial_f32));
+        return RPF_OK;
+    }
     HIP_TRY(e, rpf::launch_reduce(e->d_partial, e->last_slots, e->N, d_pwr_out,
                                   /*accumulate=*/false, static_cast<hipStream_t>(hip_stream),
                                   e->plan.partial_f32, e->bigblu ? static_cast<size_t>(e->blu_M) : 0));
     if (e->fused) HIP_TRY(e, rpf::launch_fused_poison(e->d_fused_ctl, d_pwr_out, e->N, static_cast<hipStream_t>(hip_stream)));
+    return RPF_OK;
+}
+
+// Shared argument checks of the hop entries; fills frames[h] = min(repeats[h], nbytes[h] / 2N).
+static int check_hops(rpf_engine* e, const char* who, const void* const* d_streams, const size_t* nbytes,
+                      const int64_t* repeats, int H, std::vector<int64_t>* frames)
+{
+    if (!e || !d_streams || !nbytes || !repeats || H < 1)
+        return fail(e, RPF_ERR_INVALID_ARGUMENT, std::string(who) + ": NULL argument or no hop");
+    if (e->worker_running) return fail(e, RPF_ERR_INVALID_ARGUMENT, std::string(who) + ": acquisition running");
+    frames->resize(H);
+    for (int h = 0; h < H; ++h) {
+        if (repeats[h] < 0) return fail(e, RPF_ERR_INVALID_ARGUMENT, "Argument to 'repeats' must be a positive number.");
+        if (!d_streams[h] && nbytes[h]) return fail(e, RPF_ERR_INVALID_ARGUMENT, std::string(who) + ": NULL stream");
+        if (reinterpret_cast<uintptr_t>(d_streams[h]) & 1)
+            return fail(e, RPF_ERR_INVALID_ARGUMENT, std::string(who) + ": streams must be at least 2-byte aligned");
+        (*frames)[h] = std::min<int64_t>(static_cast<int64_t>(nbytes[h] / (2 * static_cast<size_t>(e->N))), repeats[h]);
+    }
+    return RPF_OK;
+}
+
+static bool is_k1(const rpf_engine* e)
+{
+    return !(e->fourstep || e->mixed || e->bluestein || e->bigblu || e->generic);
+}
+
+int rpf_max_hops_per_launch(void) { return rpf::kMaxHops; }
+
+int rpf_accumulate_device_hops(rpf_engine* e, const void* const* d_streams, const size_t* nbytes,
+                               const int64_t* repeats, int n_hops, double* d_pwr_out, void* hip_stream,
+                               int64_t* repeats_done)
+{
+    std::vector<int64_t> frames;
+    int rc = check_hops(e, "rpf_accumulate_device_hops", d_streams, nbytes, repeats, n_hops, &frames);
+    if (rc != RPF_OK) return rc;
+    if (!d_pwr_out) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_accumulate_device_hops: NULL argument");
+    DeviceScope on_device(e->device);
+    HIP_TRY(e, on_device.status());
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (repeats_done)
+        for (int h = 0; h < n_hops; ++h) repeats_done[h] = frames[h];
+    const size_t N = static_cast<size_t>(e->N);
+    if (!is_k1(e)) {
+        // the other kernel families run one acquisition per launch set
+        for (int h = 0; h < n_hops; ++h) {
+            if (frames[h] == 0) {
+                HIP_TRY(e, hipMemsetAsync(d_pwr_out + h * N, 0, sizeof(double) * N, s));
+                continue;
+            }
+            rc = launch_frames(e, static_cast<const uint8_t*>(d_streams[h]), frames[h], d_pwr_out + h * N,
+                               /*accumulate=*/false, s);
+            if (rc != RPF_OK) return rc;
+        }
+        return RPF_OK;
+    }
+    // K1: ONE persistent launch + ONE reduce per rpf::kMaxHops hops
+    for (int h0 = 0; h0 < n_hops; h0 += rpf::kMaxHops) {
+        const int hc = std::min(rpf::kMaxHops, n_hops - h0);
+        const uint8_t* ptrs[rpf::kMaxHops];
+        for (int h = 0; h < hc; ++h) ptrs[h] = static_cast<const uint8_t*>(d_streams[h0 + h]);
+        rpf::SlotRanges slots;
+        int nslots = 0;
+        rc = launch_fused_hops(e, ptrs, frames.data() + h0, hc, s, &slots, &nslots);
+        if (rc != RPF_OK) return rc;
+        // (a hop without a whole frame has an empty slot range: the reduce writes zeros)
+        HIP_TRY(e, rpf::launch_reduce_hops(e->d_partial, slots, hc, e->N, d_pwr_out + h0 * N, /*accumulate=*/false, s,
+                                           e->plan.partial_f32));
+        e->last_slots = nslots;
+        e->last_ranges = slots;
+        e->last_hops = hc;
+    }
+    return RPF_OK;
+}
+
+int rpf_device_fused_hops(rpf_engine* e, const void* const* d_streams, const size_t* nbytes,
+                          const int64_t* repeats, int n_hops, void* hip_stream, int64_t* repeats_done)
+{
+    std::vector<int64_t> frames;
+    int rc = check_hops(e, "rpf_device_fused_hops", d_streams, nbytes, repeats, n_hops, &frames);
+    if (rc != RPF_OK) return rc;
+    if (!is_k1(e) || n_hops > rpf::kMaxHops)
+        return fail(e, RPF_ERR_INVALID_ARGUMENT,
+                    "rpf_device_fused_hops: needs a size the LDS-resident kernel serves and at most rpf_max_hops_per_launch() hops");
+    DeviceScope on_device(e->device);
+    HIP_TRY(e, on_device.status());
+    if (repeats_done)
+        for (int h = 0; h < n_hops; ++h) repeats_done[h] = frames[h];
+    const uint8_t* ptrs[rpf::kMaxHops];
+    for (int h = 0; h < n_hops; ++h) ptrs[h] = static_cast<const uint8_t*>(d_streams[h]);
+    int nslots = 0;
+    rc = launch_fused_hops(e, ptrs, frames.data(), n_hops, static_cast<hipStream_t>(hip_stream), &e->last_ranges, &nslots);
+    if (rc != RPF_OK) return rc;
+    e->last_slots = nslots;
+    e->last_hops = n_hops;
     return RPF_OK;
 }
 

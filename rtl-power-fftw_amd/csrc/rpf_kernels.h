@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "fft_core.h"
+#include "hop_partition.h"
 
 namespace rpf {
 
@@ -34,12 +35,22 @@ hipError_t plan_launch(int N, int vid, bool window, bool use_dma, int device, La
 hipError_t launch_fft_accum(int N, int vid, bool window, bool use_dma, const uint8_t* d_stream,
                             long nframes, const cf* d_twiddles, const float* d_window,
                             double* d_partial, int grid, hipStream_t stream, LaunchInfo* li);
+// The same over the hops of `hops` (hop_partition.h: frame f of hop h = bytes [2N f, 2N (f+1)) of
+// hops.stream[h]) in ONE launch.  Workgroup w writes one partial spectrum of N doubles per hop it
+// touches, at slot hops.slot_bias[h] + w of d_partial.  `grid` is what partition_hops returned
+// for (li->fpw, the planned grid).
+hipError_t launch_fft_accum_hops(int N, int vid, bool window, bool use_dma, const HopArgs& hops,
+                                 const cf* d_twiddles, const float* d_window, double* d_partial, int grid,
+                                 hipStream_t stream, LaunchInfo* li);
 
-// d_out[bin] = (accumulate ? d_out[bin] : 0) + sum_{s < nslots} d_partial[s*N + bin],
-// summed in slot order (deterministic).
-// slot_stride = distance between partial spectra in elements (0: N).
+// d_out[bin] = (accumulate ? d_out[bin] : 0) + sum_{s < nslots} d_partial[s*stride + bin],
+// summed in a fixed order (deterministic).
+// slot_stride = distance between partial spectra in elements (0: N).  N even.
 hipError_t launch_reduce(const double* d_partial, int nslots, int N, double* d_out,
                          bool accumulate, hipStream_t stream, bool partial_f32 = false, size_t slot_stride = 0);
+// The same for H hops in one launch: d_out[h*N + bin] from the slots [slots.begin[h], slots.begin[h+1]).
+hipError_t launch_reduce_hops(const double* d_partial, const SlotRanges& slots, int H, int N, double* d_out,
+                              bool accumulate, hipStream_t stream, bool partial_f32 = false, size_t slot_stride = 0);
 
 // ---- mixed-radix path (KM, rpf_mixed.hip): even N with prime factors 2, 3, 5 only, not a power of two: the planned
 // kernel for the sizes of mixed_plans.inc (up to 10000), the Stockham kernel for the rest up to 5120 --

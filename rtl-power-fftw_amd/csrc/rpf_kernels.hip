@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 #include <algorithm>
@@ -40,19 +41,6 @@ namespace rpf {
 
 namespace {
 
-// One 16-byte piece of the frame data a lane stages (same mapping as stage_raw),
-// loaded into registers.
-template <class G>
-__device__ __forceinline__ uint4 load_raw_piece(const uint8_t* __restrict__ stream, long fb, long nframes,
-                                                int wave, int lane, int i)
-{
-    int slot, off;
-    raw_source<G>(wave, i * 1024 + lane * 16, &slot, &off);
-    long f = fb + slot;
-    f = f < nframes ? f : nframes - 1;
-    return *reinterpret_cast<const uint4*>(stream + f * (2 * G::N) + off);
-}
-
 // Stage the raw bytes this wavefront will unpack in the iteration whose slot-0
 // frame is `fb` (wave-local, a-major layout: fft_core.h raw_source).  P/8
 // instructions per wave, each moving 64 lanes x 16 B = eight 128-byte rows.
@@ -60,7 +48,42 @@ __device__ __forceinline__ uint4 load_raw_piece(const uint8_t* __restrict__ stre
 // every iteration issues the same number of DMA instructions and the counted
 // s_waitcnt vmcnt(N) at the top of the frame loop stays exact.
 template <class G, bool DMA>
-__device__ __forceinline__ void stage_raw(const uint8_t* __restrict__ stream, long fb,
+__device__ __forceinline__ void stage_raw(const uint8_t* __restrict__ stream, int fb,
+                                          int nframes, uint8_t* wave_raw, int wave, int lane)
+{
+    constexpr int PIECES = G::P / 8;
+    constexpr int FRAME_BYTES = 2 * G::N;
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int j = i * 1024 + lane * 16;
+        int slot, off;
+        raw_source<G>(wave, j, &slot, &off);
+        int f = fb + slot;
+        f = f < nframes ? f : nframes - 1;
+        const uint8_t* src = stream + static_cast<long>(f) * FRAME_BYTES + off;
+        if constexpr (DMA) {
+            // LDS address = wave-uniform base + 16 * lane (added by the hardware)
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wave_raw + i * 1024), 16, 0, 0);
+        } else {
+            *reinterpret_cast<uint4*>(wave_raw + j) = *reinterpret_cast<const uint4*>(src);
+        }
+    }
+}
+
+// ---- K1, one acquisition per launch ------------------------------------------------------
+// Frame f -> workgroup (f / FPW) mod grid: at any moment the grid reads one contiguous window of
+// the stream.  (The scan kernel below walks several acquisitions per launch; for a single one
+// this plain form measured 1.2 us per launch faster on the same box -- A/B in
+// profiles/r03_k1_fixed_cost.txt -- so rpf_accumulate / rpf_accumulate_device keep it.)
+// (64-bit frame indices: the single-acquisition kernel)
+// Stage the raw bytes this wavefront will unpack in the iteration whose slot-0
+// frame is `fb` (wave-local, a-major layout: fft_core.h raw_source).  P/8
+// instructions per wave, each moving 64 lanes x 16 B = eight 128-byte rows.
+// Frames past the end are clamped to the last frame (never accumulated) so that
+// every iteration issues the same number of DMA instructions and the counted
+// s_waitcnt vmcnt(N) at the top of the frame loop stays exact.
+template <class G, bool DMA>
+__device__ __forceinline__ void stage_raw64(const uint8_t* __restrict__ stream, long fb,
                                           long nframes, uint8_t* wave_raw, int wave, int lane)
 {
     constexpr int PIECES = G::P / 8;
@@ -82,28 +105,9 @@ __device__ __forceinline__ void stage_raw(const uint8_t* __restrict__ stream, lo
     }
 }
 
-// DBUF: two slabs used alternately.  With one slab the pass-1 store of frame f+1
-// must wait (workgroup barrier at the top of the loop) until every wave has
-// finished reading frame f's slab; with two, the single barrier after the pass-1
-// store orders both hazards and a frame costs one s_barrier instead of two, at
-// the price of LDS (fewer resident workgroups).
-//
-// RAWD: depth of the raw-byte ring = frames staged ahead by LDS-DMA.  The HBM
-// latency seen by a DMA under load is several frame times (measured ~3 us vs
-// ~1 us of butterflies per frame), so one frame ahead leaves the workgroup idle
-// most of the time; RAWD frames ahead keep RAWD x 2N bytes per workgroup in flight.
-// ACCB > 0 (tuning variants): |X|^2 is first summed over ACCB frames in packed
-// float32 (one v_pk_fma_f32 per bin instead of four half-rate f64 instructions)
-// and only then folded into the f64 accumulators -- adds <= ~1e-7 relative error
-// per batch, averaged down over the batches.  PF32: partial spectra leave as
-// float32 (half the flush and K3 traffic; each partial is a sum over ~13 frames
-// and there are hundreds of them, so the rounding averages out to ~1e-9).
-__device__ unsigned int g_cu_tickets[1024];   // SKEW variants: arrival counters per CU (never reset: used modulo)
 
-// SKEW (tuning): workgroups that share a CU start SKEW x 64 cycles apart (by the slot their
-// waves got on the SIMD), so that their VALU and LDS phases interleave instead of colliding.
 template <class G, int WG, int OCC, bool WINDOW, bool DMA, bool DBUF, int ACCB = 0, bool PF32 = false,
-          int RAWD = 2, int ABL = 0, bool TWLDS = false, bool RAWREG = false, int SKEW = 0>
+          int RAWD = 2, int ABL = 0, bool TWLDS = false>
 __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __restrict__ stream,
                                                             long nframes,
                                                             const cf* __restrict__ twN,
@@ -133,16 +137,10 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
     // cycles, an LDS-DMA instruction ~100-200).
     const long stride = static_cast<long>(gridDim.x) * FPW;
     long fb = static_cast<long>(blockIdx.x) * FPW;
-    uint4 pre[RAWREG ? PIECES : 1];
     if (fb < nframes) {
-        if constexpr (RAWREG) {
 #pragma unroll
-            for (int i = 0; i < PIECES; ++i) pre[i] = load_raw_piece<G>(stream, fb, nframes, wave, lane, i);
-        } else {
-#pragma unroll
-            for (int d = 0; d < RAWD; ++d)
-                stage_raw<G, DMA>(stream, fb + d * stride, nframes, wave_raw + d * RAW_SLOT, wave, lane);
-        }
+        for (int d = 0; d < RAWD; ++d)
+            stage_raw64<G, DMA>(stream, fb + d * stride, nframes, wave_raw + d * RAW_SLOT, wave, lane);
     }
 
     // Loop-invariant per-thread constants: twiddles, sign, window.
@@ -168,22 +166,6 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
         for (int a = 0; a < P; ++a) acc32[a] = 0.0f;
     }
 
-    if constexpr (SKEW > 0) {
-        // the k-th workgroup to arrive on this CU (ticket from a per-CU counter keyed by
-        // HW_REG_XCC_ID and HW_REG_HW_ID's se/sh/cu fields) starts k x SKEW cycles late
-        constexpr int PER_CU = OCC * 256 / WG;
-        int* const box = reinterpret_cast<int*>(smem);          // the slab is not in use yet
-        if (tid == 0) {
-            const unsigned cu = __builtin_amdgcn_s_getreg((6 << 11) | (8 << 6) | 4);     // HW_ID[14:8]
-            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);   // XCC_ID[3:0]
-            box[0] = static_cast<int>(atomicAdd(&g_cu_tickets[((xcc << 7) | cu) & 1023u], 1u) % PER_CU);
-        }
-        exchange_sync<true>();
-        const int ticket = box[0];
-        exchange_sync<true>();
-#pragma unroll 1
-        for (int k = 0; k < ticket * (SKEW / 512); ++k) __builtin_amdgcn_s_sleep(8);
-    }
     PhaseClock clk;
     clk.start();
     for (int it = 0; fb < nframes; fb += stride, ++it) {
@@ -192,21 +174,7 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
         uint8_t* const ring_slot = wave_raw + (it % RAWD) * RAW_SLOT;
         cf x[P];
 
-        if constexpr (RAWREG) {
-            // this frame's bytes sit in VGPRs: drop them into the wave's raw slot, then
-            // start the loads of the next frame into the same registers
-#pragma unroll
-            for (int i = 0; i < PIECES; ++i) *reinterpret_cast<uint4*>(ring_slot + i * 1024 + lane * 16) = pre[i];
-#pragma unroll
-            for (int i = 0; i < PIECES; ++i) pre[i] = load_raw_piece<G>(stream, fb + stride, nframes, wave, lane, i);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            exchange_sync<false>();
-            RPF_STAMP(clk, 0);
-            phase_unpack<G, WINDOW>(ring_slot + 2 * lane, sgn, wsgn, x);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            exchange_sync<false>();
-            RPF_STAMP(clk, 1);
-        } else {
+        {
             // this frame's bytes have landed: every iteration issues exactly PIECES DMA
             // instructions per wave, so all but the newest (RAWD-1) frames' worth are done
             if constexpr (DMA && !(ABL & 8))
@@ -222,7 +190,7 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
             RPF_STAMP(clk, 1);                   // unpack
             // the slot has been consumed: refill it with the frame RAWD iterations ahead
             if constexpr (!(ABL & 8))
-                stage_raw<G, DMA>(stream, fb + RAWD * stride, nframes, ring_slot, wave, lane);
+                stage_raw64<G, DMA>(stream, fb + RAWD * stride, nframes, ring_slot, wave, lane);
             RPF_STAMP(clk, 3);                   // DMA issue
         }
 
@@ -301,54 +269,157 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
     }
 }
 
-// K1, alternating form (N = 2048 / 4096: several frames per 512-thread workgroup, a frame spans
-// more than one wavefront).  In fft_accum_kernel the frames of a workgroup run in lock-step: every
-// wave is in its butterflies at the same time (the LDS idles) and in its exchange at the same time
-// (the VALUs idle) -- measured, a frame round costs the SUM of its VALU and LDS phases.  Here the
-// frame slots form two groups that run half an iteration apart, swapping roles at each of the two
-// workgroup barriers a frame needs anyway:
-//     half-step h:   group 0: phase (h & 1) of frame h / 2,   group 1: phase ((h - 1) & 1) of frame (h - 1) / 2
-//     phase 0: [|X|^2 of the previous frame] unpack, pass-1 butterflies, pass-1 store
-//     phase 1: pass-2 fetch ... last pass
-// so that on every SIMD one wave's arithmetic runs beside the other wave's LDS traffic and
-// barrier wait.  Same arithmetic per frame as fft_accum_kernel: results are bit-identical.
-template <class G, int WG, int OCC, bool WINDOW, bool DMA, int RAWD = 2, bool TWLDS = true, bool ACC_LATE = true>
-__global__ __launch_bounds__(WG, OCC) void fft_accum_alt_kernel(const uint8_t* __restrict__ stream,
-                                                                long nframes,
-                                                                const cf* __restrict__ twN,
-                                                                const float* __restrict__ window,
-                                                                double* __restrict__ partial)
+
+// ---- K1, a scan of several acquisitions per launch -----------------------------------------
+__device__ __forceinline__ void write_lane(int& v, int uniform_value, int lane_const)
+{
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(uniform_value), "n"(lane_const));
+}
+
+struct HopLanes {
+    int v_nframes, v_begin, v_bias;
+    unsigned v_stream_lo, v_stream_hi;
+    // Scalar loads at constant offsets (a few s_load_dwordx16 through the scalar cache, the path
+    // every kernel argument takes), then one v_writelane per entry.
+    __device__ __forceinline__ void load(const HopArgs& a)
+    {
+        int nf = 0, bg = 0, bs = 0, lo = 0, hi = 0;
+#pragma unroll
+        for (int h = 0; h < kMaxHops; ++h) {
+            const uintptr_t p = reinterpret_cast<uintptr_t>(a.stream[h]);
+            write_lane(nf, a.nframes[h], h);
+            write_lane(bg, a.it_begin[h], h);
+            write_lane(bs, a.slot_bias[h], h);
+            write_lane(lo, static_cast<int>(static_cast<unsigned>(p)), h);
+            write_lane(hi, static_cast<int>(static_cast<unsigned>(p >> 32)), h);
+        }
+        write_lane(bg, a.it_begin[kMaxHops], kMaxHops);
+        v_nframes = nf;
+        v_begin = bg;
+        v_bias = bs;
+        v_stream_lo = static_cast<unsigned>(lo);
+        v_stream_hi = static_cast<unsigned>(hi);
+    }
+    __device__ __forceinline__ int it_begin(int h) const { return __builtin_amdgcn_readlane(v_begin, h); }
+    __device__ __forceinline__ int nframes(int h) const { return __builtin_amdgcn_readlane(v_nframes, h); }
+    __device__ __forceinline__ int slot_bias(int h) const { return __builtin_amdgcn_readlane(v_bias, h); }
+    __device__ __forceinline__ const uint8_t* stream(int h) const
+    {
+        const uintptr_t lo = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v_stream_lo), h));
+        const uintptr_t hi = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v_stream_hi), h));
+        return reinterpret_cast<const uint8_t*>(lo | (hi << 32));
+    }
+    // number of hop starts 1 .. kMaxHops at or before `it` (HopArgsView::hop_of)
+    __device__ __forceinline__ int hop_of(int it) const
+    {
+        const int lane = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(lane >= 1 && lane <= kMaxHops && v_begin <= it);
+        return __builtin_popcountll(m);
+    }
+};
+
+// DBUF: two slabs used alternately.  With one slab the pass-1 store of frame f+1
+// must wait (workgroup barrier at the top of the loop) until every wave has
+// finished reading frame f's slab; with two, the single barrier after the pass-1
+// store orders both hazards and a frame costs one s_barrier instead of two, at
+// the price of LDS (fewer resident workgroups).
+//
+// RAWD: depth of the raw-byte ring = iterations staged ahead by LDS-DMA.  The HBM
+// latency seen by a DMA under load is several frame times (measured ~3 us vs
+// ~1 us of butterflies per frame), so one frame ahead leaves the workgroup idle
+// most of the time; RAWD iterations ahead keep RAWD x 2N bytes per frame slot in flight.
+// ACCB > 0 (tuning variants): |X|^2 is first summed over ACCB frames in packed
+// float32 (one v_pk_fma_f32 per bin instead of four half-rate f64 instructions)
+// and only then folded into the f64 accumulators -- adds <= ~1e-7 relative error
+// per batch, averaged down over the batches.  PF32: partial spectra leave as
+// float32 (half the flush and K3 traffic; each partial is a sum over ~13 frames
+// and there are hundreds of them, so the rounding averages out to ~1e-9).
+//
+// One launch walks the hops of `hops` (a single acquisition is H = 1): workgroup w owns the
+// iterations [w I / G, (w + 1) I / G) of the launch's sequence and writes one partial spectrum
+// per hop it touched (slot = slot_bias[h] + w), zeroing its register accumulators in between
+// -- the reference's per-hop reset (acquisition.cxx:252-254) without a kernel boundary.
+template <class G, int WG, int OCC, bool WINDOW, bool DMA, bool DBUF, int ACCB = 0, bool PF32 = false,
+          int RAWD = 2, int ABL = 0, bool TWLDS = false>
+__global__ __launch_bounds__(WG, OCC) void fft_accum_scan_kernel(const cf* __restrict__ twN,
+                                                            const float* __restrict__ window,
+                                                            double* __restrict__ partial,
+                                                            const HopArgs hops)
 {
     constexpr int P = G::P, T = G::T, N = G::N, NPASS = G::NPASS;
     constexpr int FPW = WG / T;
-    static_assert(WG % T == 0 && T % 64 == 0 && FPW % 2 == 0, "two groups of whole wavefronts");
-    static_assert(NPASS >= 2 && (NPASS == 2 || G::Lcur(2) <= 64), "only the first exchange crosses wavefronts");
+    constexpr int NSLAB = DBUF ? 2 : 1;
+    constexpr bool BLOCK_SYNC = (T > 64);
+    static_assert(WG % T == 0 && WG % 64 == 0, "");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cf* const slab_base = reinterpret_cast<cf*>(smem);                   // [FPW][LDS_CPX]
-    uint8_t* const raw_base = smem + FPW * G::LDS_CPX * sizeof(cf);      // [WG/64][RAWD][128 P]
+    cf* const slab_base = reinterpret_cast<cf*>(smem);                        // [NSLAB][FPW][LDS_CPX]
+    uint8_t* const raw_base = smem + NSLAB * FPW * G::LDS_CPX * sizeof(cf);  // [WG/64][RAWD][128 P]
 
     const int tid = threadIdx.x;
     const int fs = tid / T, t = tid % T;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int grp = ((wave * 64) / T) & 1;                               // wave-uniform
-    constexpr int RAW_SLOT = kRawChunk * P;
-    constexpr int PIECES = P / 8;
+    constexpr int RAW_SLOT = kRawChunk * P;           // bytes one wave stages per frame
+    constexpr int PIECES = P / 8;                     // DMA instructions per wave per frame
     uint8_t* const wave_raw = raw_base + wave * (RAWD * RAW_SLOT);
-    cf* const slab = slab_base + fs * G::LDS_CPX;
 
-    const long stride = static_cast<long>(gridDim.x) * FPW;
-    const long fb0 = static_cast<long>(blockIdx.x) * FPW;
-    const int iters = fb0 < nframes ? static_cast<int>((nframes - fb0 + stride - 1) / stride) : 0;
-    if (iters > 0) {
+    // This workgroup's iterations: `count` of them, `step` apart from `first` on (hop_partition.h).
+    // The host launches at most one workgroup per iteration (launch_fft_accum checks it), so
+    // count >= 1 -- deliberately not tested here: a branch on q and r would put their scalar
+    // load in front of the table loads instead of beside them.
+    HopLanes tbl;
+    tbl.load(hops);
+    const int step = hops.step;
+    int first, count;
+    hop_share(static_cast<int>(blockIdx.x), hops.q, hops.r, step, &first, &count);
+
+    // First thing: get the first iterations' bytes moving (HBM latency overlaps the constant
+    // loads below).  The staging cursor `ahead` runs RAWD iterations in front of the compute
+    // cursor, across hop boundaries; every iteration issues PIECES DMAs.  The frame loop sees
+    // of it only a frame index that advances and a countdown: `ahead_run` stagings stay inside
+    // the hop the cursor stands in (scans have step = 1, an interleaved single acquisition
+    // never leaves its hop), then ahead_turn() moves the cursor on -- or, when nothing is left
+    // to stage, parks it on the launch's iteration 0 with no advance: the same 2N FPW bytes
+    // for every workgroup, an L2 hit, so the surplus (never read) stagings that keep the DMA
+    // count per iteration constant cost no memory traffic.
+    const int fstep = FPW * step;                  // frames between a workgroup's iterations
+    HopCursor ahead;
+    ahead.seek(tbl, first);
+    int ahead_fb = (ahead.j - ahead.begin) * FPW, ahead_fstep = fstep;
+    int ahead_left = count;                        // real iterations not staged yet
+    auto run_length = [&](const HopCursor& c, int left) {
+        const int in_hop = step == 1 ? c.end - c.j : left;
+        return in_hop < left ? in_hop : left;
+    };
+    int ahead_run = run_length(ahead, ahead_left);
+    ahead_left -= ahead_run;
+    auto ahead_turn = [&]() {
+        if (ahead_left > 0) {
+            ahead.seek(tbl, ahead.end);            // (step == 1 here: the next hop starts where this one ended)
+            ahead_fb = 0;
+            ahead_run = run_length(ahead, ahead_left);
+            ahead_left -= ahead_run;
+        } else {
+            ahead.seek(tbl, 0);
+            ahead_fb = 0;
+            ahead_fstep = 0;
+            ahead_run = 0x7fffffff;
+        }
+    };
+    auto stage_next = [&](uint8_t* dst) {
+        stage_raw<G, DMA>(ahead.stream, ahead_fb, ahead.nframes, dst, wave, lane);
+        ahead_fb += ahead_fstep;
+        if (--ahead_run == 0) ahead_turn();
+    };
+    if constexpr (!(ABL & 8)) {
 #pragma unroll
-        for (int d = 0; d < RAWD; ++d)
-            stage_raw<G, DMA>(stream, fb0 + d * stride, nframes, wave_raw + d * RAW_SLOT, wave, lane);
+        for (int d = 0; d < RAWD; ++d) stage_next(wave_raw + d * RAW_SLOT);
     }
 
+    // Loop-invariant per-thread constants: twiddles, sign, window.
     cf tw[NPASS - 1][P - 1];
     load_twiddles<G, 1, TWLDS>(t, twN, tw);
-    cf* const twtable = reinterpret_cast<cf*>(raw_base + (WG / 64) * RAWD * RAW_SLOT);
+    cf* const twtable = reinterpret_cast<cf*>(raw_base + (WG / 64) * RAWD * (kRawChunk * P));
     if constexpr (TWLDS) {
         fill_twlds<G, 1>(tid, WG, twN, twtable);
         exchange_sync<true>();
@@ -360,66 +431,129 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_alt_kernel(const uint8_t* _
         for (int a = 0; a < P; ++a) wsgn[a] = window[t + T * a] * sgn;
     }
     double acc[P];
-#pragma unroll
-    for (int a = 0; a < P; ++a) acc[a] = 0.0;
+    float acc32[ACCB > 0 ? P : 1];
 
     PhaseClock clk;
-    cf x[P];
-    bool pending = false;        // x holds the spectrum of a frame that has not been accumulated yet
-#pragma unroll 1
-    for (int h = 0; h <= 2 * iters; ++h) {
-        const int hh = h - grp;
-        const int it = hh >> 1;
-        if (hh >= 0 && it < iters) {
-            const long fb = fb0 + it * stride;
-            if ((hh & 1) == 0) {
-                if constexpr (ACC_LATE) {
-                    if (pending) phase_accumulate(x, acc, P);
+    clk.start();
+    HopCursor cur;
+    cur.seek(tbl, first);
+    int it = 0;                                    // iterations done: ring slot and slab parity
+    while (true) {
+        // ---- one segment: this workgroup's iterations inside hop cur.h ------------------------
+        const int seg = run_length(cur, count - it);
+#pragma unroll
+        for (int a = 0; a < P; ++a) acc[a] = 0.0;
+        if constexpr (ACCB > 0) {
+#pragma unroll
+            for (int a = 0; a < P; ++a) acc32[a] = 0.0f;
+        }
+        int fb = (cur.j - cur.begin) * FPW;        // slot-0 frame of the iteration, within the hop
+        for (int n = seg; n > 0; --n, ++it, fb += fstep) {
+            const bool active = (fb + fs) < cur.nframes;
+            cf* const slab = slab_base + ((DBUF ? (it & 1) : 0) * FPW + fs) * G::LDS_CPX;
+            uint8_t* const ring_slot = wave_raw + (it % RAWD) * RAW_SLOT;
+            cf x[P];
+
+            // this iteration's bytes have landed: every iteration issues exactly PIECES DMA
+            // instructions per wave, so all but the newest (RAWD-1) iterations' worth are done
+            if constexpr (DMA && !(ABL & 8))
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RAWD - 1) * PIECES) : "memory");
+            exchange_sync<false>();
+            RPF_STAMP(clk, 0);                   // waiting for the staged bytes
+            phase_unpack<G, WINDOW>(ring_slot + 2 * lane, sgn, wsgn, x);
+            // The slot is refilled next: its ds_read_u16 must have RETURNED first (a DMA
+            // that hits in L2/MALL can land before queued LDS reads execute -- seen as
+            // sporadic 1e-3 errors), so wait for this wave's LDS reads, not just issue.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            exchange_sync<false>();
+            RPF_STAMP(clk, 1);                   // unpack
+            // the slot has been consumed: refill it with the iteration RAWD ahead
+            if constexpr (!(ABL & 8)) stage_next(ring_slot);
+            RPF_STAMP(clk, 3);                   // DMA issue
+
+            // single slab: every wave must be done with the previous frame's slab
+            if constexpr (!DBUF) exchange_sync<BLOCK_SYNC>();
+            RPF_STAMP(clk, 2);                       // top-of-frame barrier
+            middle_passes<G, 1, ABL, TWLDS>(t, x, tw, slab, clk, twtable);   // stamps 4J..4J+3
+            if constexpr (!(ABL & 4)) phase_fetch<G, NPASS>(t, x, slab);
+            asm volatile("" : "+v"(x[0]));
+            RPF_STAMP(clk, 12);                      // last fetch
+            if constexpr (!(ABL & 2)) phase_last<G>(x);
+            RPF_STAMP(clk, 13);                      // last butterfly
+            if constexpr (ACCB > 0) {
+                if (active) {
+#pragma unroll
+                    for (int a = 0; a < P; ++a)
+                        acc32[a] = __builtin_fmaf(x[a].x, x[a].x, __builtin_fmaf(x[a].y, x[a].y, acc32[a]));
                 }
-                uint8_t* const ring_slot = wave_raw + (it % RAWD) * RAW_SLOT;
-                if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RAWD - 1) * PIECES) : "memory");
-                exchange_sync<false>();
-                phase_unpack<G, WINDOW>(ring_slot + 2 * lane, sgn, wsgn, x);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slot's reads have returned
-                exchange_sync<false>();
-                stage_raw<G, DMA>(stream, fb + RAWD * stride, nframes, ring_slot, wave, lane);
-                phase_butterfly_twiddle<G>(x, tw[0]);
-                phase_store<G, 1>(t, x, slab);
+                if ((it % ACCB) == ACCB - 1) {
+#pragma unroll
+                    for (int a = 0; a < P; ++a) {
+                        acc[a] += static_cast<double>(acc32[a]);
+                        acc32[a] = 0.0f;
+                    }
+                }
+            } else if constexpr (ABL & 1) {
+#pragma unroll
+                for (int a = 0; a < P; ++a) asm volatile("" ::"v"(x[a]));
             } else {
-                if constexpr (NPASS > 2) middle_passes<G, 2, 0, TWLDS>(t, x, tw, slab, clk, twtable);
-                phase_fetch<G, NPASS>(t, x, slab);
-                phase_last<G>(x);
-                const bool active = (fb + fs) < nframes;
-                if constexpr (ACC_LATE) {
-                    pending = active;
-                } else {
-                    if (active) phase_accumulate(x, acc, P);
+                if (active) phase_accumulate(x, acc, P);
+            }
+            RPF_STAMP(clk, 14);                      // accumulate
+        }
+        if constexpr (ACCB > 0) {
+#pragma unroll
+            for (int a = 0; a < P; ++a) acc[a] += static_cast<double>(acc32[a]);
+        }
+
+        // ---- hand the segment over: one partial spectrum (the FPW frame slots summed) ----------
+        // The accumulators go through the slab (free between frames; the raw ring with its
+        // in-flight prefetches is not touched) so that the bin-scattered registers leave as
+        // fully coalesced 512-byte rows: stage at a padded bin index (one spare double per
+        // 16, conflict-free for the stride-16 bin pattern of bin_of), then stream out.
+        exchange_sync<true>();
+        double* const stage = reinterpret_cast<double*>(smem);          // [FPW][N + N/16]
+        constexpr int SN = N + N / 16;
+        static_assert(sizeof(double) * SN <= sizeof(cf) * G::LDS_CPX, "the stage stays inside the slab");
+        // (opaque copies of the thread indices: the hand-over runs once per hop, its sixteen
+        // stage addresses must not be hoisted into registers that live across the frame loop)
+        int ft = t, ftid = tid, ffs = fs;
+        asm volatile("" : "+v"(ft), "+v"(ftid), "+v"(ffs));
+#pragma unroll
+        for (int a = 0; a < P; ++a) {
+            const int bin = bin_of<G>(ft, a);
+            stage[ffs * SN + bin + (bin >> 4)] = acc[a];
+        }
+        exchange_sync<true>();
+        const size_t slot = static_cast<size_t>(tbl.slot_bias(cur.h) + static_cast<int>(blockIdx.x));
+        if constexpr (PF32) {
+            for (int bin = ftid; bin < N; bin += WG) {
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < FPW; ++k) v += stage[k * SN + bin + (bin >> 4)];
+                reinterpret_cast<float*>(partial)[slot * N + bin] = static_cast<float>(v);
+            }
+        } else {
+            // two neighbouring bins per lane = one 16-byte store: an 8-byte-per-lane store tail is
+            // issue-bound at ~7 B/clk/CU (MI355X_MICROARCH.md), and every workgroup ends in one
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            for (int bin = 2 * ftid; bin < N; bin += 2 * WG) {
+                d2 v = {0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < FPW; ++k) {
+                    v.x += stage[k * SN + bin + (bin >> 4)];
+                    v.y += stage[k * SN + bin + 1 + (bin >> 4)];
                 }
+                *reinterpret_cast<d2*>(partial + slot * N + bin) = v;
             }
         }
-        exchange_sync<true>();       // the two groups swap roles
+        if (it >= count) break;
+        // next hop: the slab is reused by its first frame once every wave has read the stage
+        exchange_sync<true>();
+        cur.seek(tbl, cur.end);                    // (a segment that is not the last ends with its hop)
     }
-    if constexpr (ACC_LATE) {
-        if (pending) phase_accumulate(x, acc, P);
-    }
-    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (clamped) prefetches
-
-    exchange_sync<true>();
-    double* const stage = reinterpret_cast<double*>(smem);          // [FPW][N + N/16]
-    constexpr int SN = N + N / 16;
-    static_assert(sizeof(double) * SN <= sizeof(cf) * G::LDS_CPX + 2 * N, "stage fits the LDS");
-#pragma unroll
-    for (int a = 0; a < P; ++a) {
-        const int bin = bin_of<G>(t, a);
-        stage[fs * SN + bin + (bin >> 4)] = acc[a];
-    }
-    exchange_sync<true>();
-    for (int bin = tid; bin < N; bin += WG) {
-        double v = 0.0;
-#pragma unroll
-        for (int k = 0; k < FPW; ++k) v += stage[k * SN + bin + (bin >> 4)];
-        partial[static_cast<size_t>(blockIdx.x) * N + bin] = v;
-    }
+    clk.publish(lane);
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (repeated) prefetches
 }
 
 // KB  bluestein_kernel -- any even N <= 4096 that is not one of K1's powers of two
@@ -512,58 +646,74 @@ __global__ __launch_bounds__(WG, OCC) void bluestein_kernel(const uint8_t* __res
     }
 }
 
-// K3.  out[bin] = (accumulate ? out[bin] : 0) + sum over workgroup partials, in
-// a fixed order (bit-reproducible for a given grid): thread (g, b) sums the
-// partials g, g+16, g+32, ... of bin b with 8 independent loads in flight, then
-// the 16 group sums are added in group order.
-constexpr int RED_BINS = 16, RED_GROUPS = 16, RED_UNROLL = 8;
-
-template <typename PT>
-__global__ __launch_bounds__(RED_BINS* RED_GROUPS) void reduce_kernel(
-    const PT* __restrict__ partial, int nslots, int N, double* __restrict__ out,
+// K3.  out[hop][bin] = (accumulate ? out[hop][bin] : 0) + the partial spectra of the hop's slot
+// range, in a fixed order (bit-reproducible for a given grid): thread (g, b) sums the slots
+// g, g+GROUPS, g+2 GROUPS, ... of the bin pair b -- 16-byte loads, UNROLL of them in flight -- then
+// the GROUPS group sums are added in group order.  blockIdx.y = hop.
+template <typename PT, int PAIRS, int GROUPS, int UNROLL>
+__global__ __launch_bounds__(PAIRS* GROUPS) void reduce_kernel(
+    const PT* __restrict__ partial, const SlotRanges slots, int N, double* __restrict__ out,
     int accumulate, size_t stride)
 {
-    __shared__ double red[RED_GROUPS][RED_BINS + 1];
-    const int b = threadIdx.x % RED_BINS, g = threadIdx.x / RED_BINS;
-    const int bin = blockIdx.x * RED_BINS + b;
-    double s = 0.0;
+    typedef PT pt2 __attribute__((ext_vector_type(2)));
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    __shared__ d2 red[GROUPS][PAIRS + 1];
+    const int hop = blockIdx.y;
+    const int first = slots.begin[hop], nslots = slots.begin[hop + 1] - first;
+    const int b = threadIdx.x % PAIRS, g = threadIdx.x / PAIRS;
+    const int bin = blockIdx.x * (2 * PAIRS) + 2 * b;            // N is even: a pair never straddles the end
+    d2 s = {0.0, 0.0};
     if (bin < N) {
-        const PT* p = partial + bin;
+        const PT* p = partial + static_cast<size_t>(first) * stride + bin;
         int sl = g;
-        for (; sl + (RED_UNROLL - 1) * RED_GROUPS < nslots; sl += RED_UNROLL * RED_GROUPS) {
-            PT v[RED_UNROLL];
+        for (; sl + (UNROLL - 1) * GROUPS < nslots; sl += UNROLL * GROUPS) {
+            pt2 v[UNROLL];
 #pragma unroll
-            for (int u = 0; u < RED_UNROLL; ++u)
-                v[u] = p[static_cast<size_t>(sl + u * RED_GROUPS) * stride];
+            for (int u = 0; u < UNROLL; ++u)
+                v[u] = *reinterpret_cast<const pt2*>(p + static_cast<size_t>(sl + u * GROUPS) * stride);
 #pragma unroll
-            for (int u = 0; u < RED_UNROLL; ++u) s += v[u];
+            for (int u = 0; u < UNROLL; ++u) {
+                s.x += v[u].x;
+                s.y += v[u].y;
+            }
         }
-        for (; sl < nslots; sl += RED_GROUPS) s += p[static_cast<size_t>(sl) * stride];
+        for (; sl < nslots; sl += GROUPS) {
+            const pt2 v = *reinterpret_cast<const pt2*>(p + static_cast<size_t>(sl) * stride);
+            s.x += v.x;
+            s.y += v.y;
+        }
     }
     red[g][b] = s;
     __syncthreads();
     if (g == 0 && bin < N) {
-        double tot = accumulate ? out[bin] : 0.0;
+        double* o = out + static_cast<size_t>(hop) * N + bin;
+        d2 tot = {0.0, 0.0};
+        if (accumulate) tot = *reinterpret_cast<const d2*>(o);
 #pragma unroll
-        for (int k = 0; k < RED_GROUPS; ++k) tot += red[k][b];
-        out[bin] = tot;
+        for (int k = 0; k < GROUPS; ++k) {
+            tot.x += red[k][b].x;
+            tot.y += red[k][b].y;
+        }
+        *reinterpret_cast<d2*>(o) = tot;
     }
 }
 
 // ---------------------------------------------------------------- dispatch --
-using KernelFn = void (*)(const uint8_t*, long, const cf*, const float*, double*);
+using SingleFn = void (*)(const uint8_t*, long, const cf*, const float*, double*);
+using ScanFn = void (*)(const cf*, const float*, double*, const HopArgs);
 
 struct Variant {
     int N, vid, P, WG, fpw, lds_bytes;
     bool partial_f32;
-    KernelFn fn[2][2];   // [window][dma]
+    SingleFn single[2][2];   // [window][dma]: one acquisition per launch
+    ScanFn scan[2][2];       // several hops per launch
 };
 
 // OCC (OCCW for the windowed kernels) = waves per SIMD the register budget
 // must admit (= resident workgroups per CU x WG/256).  vid = tuning variant
 // (0 = the default for this N).
 template <int N, int P, int OCC, int OCCW = OCC, bool DBUF = false, int ACCB = 0, bool PF32 = false,
-          int RAWD = 2, int ABL = 0, bool TWLDS = false, bool RAWREG = false, int WGO = 0, int SKEW = 0>
+          int RAWD = 2, int ABL = 0, bool TWLDS = false, int WGO = 0>
 Variant make_variant(int vid)
 {
     using G = Geom<N, P>;
@@ -572,29 +722,18 @@ Variant make_variant(int vid)
     constexpr int LDS = FPW * ((DBUF ? 2 : 1) * G::LDS_CPX * (int)sizeof(cf) + RAWD * 2 * N) +
                         (TWLDS ? twlds_entries<G>() * (int)sizeof(cf) : 0);
     return Variant{N, vid, P, WG, FPW, LDS, PF32,
-                   {{fft_accum_kernel<G, WG, OCC, false, false, DBUF, ACCB, PF32, RAWD, ABL, TWLDS, RAWREG, SKEW>,
-                     fft_accum_kernel<G, WG, OCC, false, true, DBUF, ACCB, PF32, RAWD, ABL, TWLDS, RAWREG, SKEW>},
-                    {fft_accum_kernel<G, WG, OCCW, true, false, DBUF, ACCB, PF32, RAWD, ABL, TWLDS, RAWREG, SKEW>,
-                     fft_accum_kernel<G, WG, OCCW, true, true, DBUF, ACCB, PF32, RAWD, ABL, TWLDS, RAWREG, SKEW>}}};
-}
-
-// the alternating form: WG threads = WG / T frame slots in two groups half an iteration apart
-template <int N, int P, int WG, int OCC, int RAWD = 2, bool TWLDS = true, bool ACC_LATE = true>
-Variant make_alt_variant(int vid)
-{
-    using G = Geom<N, P>;
-    constexpr int FPW = WG / G::T;
-    constexpr int LDS = FPW * (G::LDS_CPX * (int)sizeof(cf) + RAWD * 2 * N) +
-                        (TWLDS ? twlds_entries<G>() * (int)sizeof(cf) : 0);
-    return Variant{N, vid, P, WG, FPW, LDS, false,
-                   {{fft_accum_alt_kernel<G, WG, OCC, false, false, RAWD, TWLDS, ACC_LATE>,
-                     fft_accum_alt_kernel<G, WG, OCC, false, true, RAWD, TWLDS, ACC_LATE>},
-                    {fft_accum_alt_kernel<G, WG, OCC, true, false, RAWD, TWLDS, ACC_LATE>,
-                     fft_accum_alt_kernel<G, WG, OCC, true, true, RAWD, TWLDS, ACC_LATE>}}};
+                   {{fft_accum_kernel<G, WG, OCC, false, false, DBUF, ACCB, PF32, RAWD, ABL, TWLDS>,
+                     fft_accum_kernel<G, WG, OCC, false, true, DBUF, ACCB, PF32, RAWD, ABL, TWLDS>},
+                    {fft_accum_kernel<G, WG, OCCW, true, false, DBUF, ACCB, PF32, RAWD, ABL, TWLDS>,
+                     fft_accum_kernel<G, WG, OCCW, true, true, DBUF, ACCB, PF32, RAWD, ABL, TWLDS>}},
+                   {{fft_accum_scan_kernel<G, WG, OCC, false, false, DBUF, ACCB, PF32, RAWD, ABL, TWLDS>,
+                     fft_accum_scan_kernel<G, WG, OCC, false, true, DBUF, ACCB, PF32, RAWD, ABL, TWLDS>},
+                    {fft_accum_scan_kernel<G, WG, OCCW, true, false, DBUF, ACCB, PF32, RAWD, ABL, TWLDS>,
+                     fft_accum_scan_kernel<G, WG, OCCW, true, true, DBUF, ACCB, PF32, RAWD, ABL, TWLDS>}}};
 }
 
 const Variant kVariants[] = {
-    // defaults.  Template arguments after <N, P>: OCC, OCCW, DBUF, ACCB, PF32, RAWD, ABL, TWLDS
+    // defaults.  Template arguments after <N, P>: OCC, OCCW, DBUF, ACCB, PF32, RAWD, ABL, TWLDS, WGO
     // 128 = 16 x 8 and 256 = 16 x 16: two passes and ONE exchange at 16 points per lane (measured
     // 12-14 % faster than 8 x 8 x 2 / 8 x 8 x 4 -- the LDS stores are what costs)
     make_variant<64, 8, 4, 4, false, 0, false, 4>(0),    make_variant<128, 16, 3, 3, false, 0, false, 4>(0),
@@ -602,67 +741,51 @@ const Variant kVariants[] = {
     make_variant<1024, 16, 3, 2, false, 0, false, 2, 0, true>(0),
     // 2048/4096: one 512-thread workgroup per CU (4 / 2 frames side by side): as fast as three
     // 256-thread workgroups (the kernel is VALU-bound at 8 waves) and a third of the partials.
-    make_variant<2048, 16, 2, 2, false, 0, false, 2, 0, true, false, 512>(0),
-    make_variant<4096, 16, 2, 2, false, 0, false, 2, 0, true, false, 512>(0),
+    make_variant<2048, 16, 2, 2, false, 0, false, 2, 0, true, 512>(0),
+    make_variant<4096, 16, 2, 2, false, 0, false, 2, 0, true, 512>(0),
     make_variant<8192, 16, 2, 2, false, 0, false, 2>(0),
 #ifdef RPF_TUNING
     // Lab equipment, compiled only into the -DRPF_TUNING build (make tuning ->
     // librpf_engine_tuning.so, used by tools/): in the shipped library every N has exactly
     // one kernel and RPF_FLAG_VARIANT(k != 0) fails rpf_engine_create with
     // RPF_ERR_INVALID_ARGUMENT.  Every variant is exact unless it says float32 or ablation.
+    // (Round 2's de-phasing experiments -- alternating frame groups, skewed workgroup starts,
+    // register prefetch instead of LDS-DMA -- measured slower and were removed in round 3;
+    // their numbers stay in profiles/r02_k1_dephasing.txt and DESIGN.md.)
     make_variant<4096, 16, 3, 2, false, 0, false, 2>(1),              // all twiddles in registers
     make_variant<4096, 16, 3, 2, false, 0, false, 1, 0, true>(2),     // one frame ahead only
     make_variant<4096, 16, 2, 2, true, 0, false, 2, 0, true>(3),      // double-buffered slab (one barrier per frame)
     make_variant<4096, 16, 3, 3, false, 8, true, 2, 0, true>(4),      // float32 batch accumulate + float32 partials
     make_variant<4096, 8, 4, 4, false, 0, false, 2>(5),               // 8 points per lane, 512 threads
-    make_variant<4096, 16, 3, 3, false, 0, false, 2, 0, true, false, 768>(8),   // one 768-thread workgroup per CU, 3 frames side by side
+    make_variant<4096, 16, 3, 3, false, 0, false, 2, 0, true, 768>(8),   // one 768-thread workgroup per CU, 3 frames side by side
     make_variant<4096, 16, 3, 2, false, 0, false, 2, 0, true>(9),               // 256 threads, 3 (windowed: 2) workgroups per CU
     make_variant<4096, 16, 2, 2, false, 0, false, 2, 0, true>(10),              // 256 threads, 2 workgroups per CU
-    make_variant<4096, 16, 2, 2, false, 8, false, 2, 0, true, false, 512>(22),  // 512 threads, float32 batch accumulate, f64 partials
-    make_variant<4096, 16, 2, 2, true, 0, false, 1, 0, true, false, 512>(26),   // 512 threads, double-buffered slab (no top barrier), raw ring 1
-    make_variant<4096, 16, 3, 2, false, 0, false, 1, 0, true, true>(6),   // next frame prefetched in VGPRs, no LDS-DMA
-    make_variant<4096, 16, 3, 3, false, 8, true, 1, 0, true, true>(7),    // same + float32 batch accumulate/partials
+    make_variant<4096, 16, 2, 2, false, 8, false, 2, 0, true, 512>(22),  // 512 threads, float32 batch accumulate, f64 partials
+    make_variant<4096, 16, 2, 2, true, 0, false, 1, 0, true, 512>(26),   // 512 threads, double-buffered slab (no top barrier), raw ring 1
+    // round 3: deeper raw rings for HBM-resident input (one workgroup per CU leaves the LDS for it),
+    // pass-2 twiddles back in registers (the 512-thread form has the registers)
+    make_variant<4096, 16, 2, 2, false, 0, false, 3, 0, true, 512>(50),
+    make_variant<4096, 16, 2, 2, false, 0, false, 4, 0, true, 512>(51),
+    make_variant<4096, 16, 2, 2, false, 0, false, 6, 0, true, 512>(52),
+    make_variant<4096, 16, 2, 2, false, 0, false, 2, 0, false, 512>(53),
+    make_variant<4096, 16, 2, 2, false, 0, false, 4, 0, false, 512>(54),
+    make_variant<2048, 16, 2, 2, false, 0, false, 4, 0, true, 512>(51),
     make_variant<512, 8, 4, 4, false, 0, false, 4>(1),  make_variant<512, 8, 4, 4, false, 0, false, 8>(2),
     make_variant<512, 16, 3, 3, false, 0, false, 2>(3),
     make_variant<128, 8, 4, 4, false, 0, false, 4>(3),   make_variant<256, 8, 4, 4, false, 0, false, 4>(3),    // 8 points per lane, three passes
     make_variant<1024, 8, 4, 4, false, 0, false, 4>(1), make_variant<2048, 8, 4, 4, false, 0, false, 4>(1),
     make_variant<1024, 16, 3, 3, false, 0, false, 2>(2), make_variant<2048, 16, 3, 3, false, 0, false, 2>(2),
-    make_variant<1024, 16, 2, 2, false, 0, false, 2, 0, true, false, 512>(9),
+    make_variant<1024, 16, 2, 2, false, 0, false, 2, 0, true, 512>(9),
     make_variant<2048, 16, 3, 2, false, 0, false, 2, 0, true>(9),
-    make_variant<512, 8, 2, 2, false, 0, false, 2, 0, false, false, 512>(9),
+    make_variant<512, 8, 2, 2, false, 0, false, 2, 0, false, 512>(9),
     make_variant<8192, 16, 2, 2, false, 0, false, 2, 0, true>(1),
-    // round 2: de-phasing experiments
-    make_alt_variant<4096, 16, 512, 2>(40),                    // alternating groups, |X|^2 deferred into phase 0
-    make_alt_variant<4096, 16, 512, 2, 2, true, false>(41),    // alternating groups, |X|^2 at the end of phase 1
-    make_alt_variant<4096, 16, 512, 2, 1>(42),                 // ... raw ring of one frame
-    make_alt_variant<2048, 16, 512, 2>(40),
-    make_alt_variant<2048, 16, 512, 2, 2, true, false>(41),
-    make_alt_variant<1024, 16, 512, 2>(40),                    // (T = 64: one wavefront per frame, 8 slots)
-    // independent 256-thread workgroups, the k-th on a CU started k x SKEW cycles late
-    make_variant<4096, 16, 3, 2, false, 0, false, 2, 0, true, false, 0, 1536>(43),
-    make_variant<4096, 16, 3, 2, false, 0, false, 2, 0, true, false, 0, 2560>(44),
-    make_variant<4096, 16, 3, 2, false, 0, false, 2, 0, true, false, 0, 3584>(45),
-    make_variant<4096, 16, 2, 2, false, 0, false, 2, 0, true, false, 0, 2560>(46),
-    make_variant<4096, 16, 2, 2, false, 0, false, 2, 0, true, false, 0, 4096>(47),
-    make_variant<4096, 16, 3, 2, false, 0, false, 2, 0, true, false, 0, 512>(48),
-    make_variant<4096, 16, 3, 2, false, 0, false, 1, 0, true, false, 0, 2560>(49),     // raw ring of one frame
     // measurement-only ablations of the default N=4096 kernel (results are garbage)
-    make_variant<4096, 16, 3, 2, false, 0, false, 2, 1, true>(11),    // no accumulate
-    make_variant<4096, 16, 3, 2, false, 0, false, 2, 2, true>(12),    // no butterfly arithmetic
-    make_variant<4096, 16, 3, 2, false, 0, false, 2, 4, true>(13),    // no LDS exchanges
-    make_variant<4096, 16, 3, 2, false, 0, false, 2, 8, true>(14),    // no HBM staging
-    make_variant<4096, 16, 3, 2, false, 0, false, 2, 6, true>(15),    // no arithmetic, no exchanges
-    make_variant<4096, 16, 3, 2, false, 0, false, 2, 3, true>(16),    // no arithmetic at all
-    make_variant<4096, 16, 3, 2, false, 0, false, 2, 12, true>(17),   // butterflies + accumulate only (no exchanges, no staging)
-    make_variant<4096, 16, 3, 2, false, 0, false, 2, 13, true>(18),   // butterflies only
-    make_variant<4096, 16, 3, 2, false, 0, false, 2, 14, true>(19),   // accumulate only (+ barriers, unpack)
-    // the same ablations on the default 512-thread configuration
-    make_variant<4096, 16, 2, 2, false, 0, false, 2, 1, true, false, 512>(31),    // no accumulate
-    make_variant<4096, 16, 2, 2, false, 0, false, 2, 2, true, false, 512>(32),    // no butterfly arithmetic
-    make_variant<4096, 16, 2, 2, false, 0, false, 2, 4, true, false, 512>(34),    // no LDS exchanges
-    make_variant<4096, 16, 2, 2, false, 0, false, 2, 8, true, false, 512>(38),    // no HBM staging
-    make_variant<4096, 16, 2, 2, false, 0, false, 2, 13, true, false, 512>(36),   // butterflies only
-    make_variant<4096, 16, 2, 2, false, 0, false, 2, 12, true, false, 512>(37),   // butterflies + accumulate only
+    make_variant<4096, 16, 2, 2, false, 0, false, 2, 1, true, 512>(31),    // no accumulate
+    make_variant<4096, 16, 2, 2, false, 0, false, 2, 2, true, 512>(32),    // no butterfly arithmetic
+    make_variant<4096, 16, 2, 2, false, 0, false, 2, 4, true, 512>(34),    // no LDS exchanges
+    make_variant<4096, 16, 2, 2, false, 0, false, 2, 8, true, 512>(38),    // no HBM staging
+    make_variant<4096, 16, 2, 2, false, 0, false, 2, 13, true, 512>(36),   // butterflies only
+    make_variant<4096, 16, 2, 2, false, 0, false, 2, 12, true, 512>(37),   // butterflies + accumulate only
 #endif  // RPF_TUNING
 };
 
@@ -725,16 +848,20 @@ hipError_t plan_launch(int N, int vid, bool window, bool use_dma, int device, La
 {
     const Variant* v = find_variant(N, vid);
     if (!v) return hipErrorInvalidValue;
-    KernelFn fn = v->fn[window ? 1 : 0][use_dma ? 1 : 0];
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, v->lds_bytes);
-    if (err != hipSuccess) return err;
-    int per_cu = 0;
-    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn),
-                                                       v->WG, v->lds_bytes);
-    if (err != hipSuccess) return err;
+    int per_cu = 1 << 30;
+    for (int scan = 0; scan < 2; ++scan) {          // the single-acquisition and the scan instantiation share one grid
+        const void* fn = scan ? reinterpret_cast<const void*>(v->scan[window ? 1 : 0][use_dma ? 1 : 0])
+                              : reinterpret_cast<const void*>(v->single[window ? 1 : 0][use_dma ? 1 : 0]);
+        hipError_t err = hipFuncSetAttribute(fn,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, v->lds_bytes);
+        if (err != hipSuccess) return err;
+        int n = 0;
+        err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, v->WG, v->lds_bytes);
+        if (err != hipSuccess) return err;
+        per_cu = std::min(per_cu, n);
+    }
     hipDeviceProp_t prop;
-    err = hipGetDeviceProperties(&prop, device);
+    hipError_t err = hipGetDeviceProperties(&prop, device);
     if (err != hipSuccess) return err;
     if (per_cu < 1) per_cu = 1;
     li->grid = per_cu * prop.multiProcessorCount;
@@ -751,9 +878,26 @@ hipError_t launch_fft_accum(int N, int vid, bool window, bool use_dma, const uin
 {
     const Variant* v = find_variant(N, vid);
     if (!v || grid < 1) return hipErrorInvalidValue;
-    KernelFn fn = v->fn[window ? 1 : 0][use_dma ? 1 : 0];
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(v->WG), v->lds_bytes, stream, d_stream, nframes,
-                       d_twiddles, d_window, d_partial);
+    hipLaunchKernelGGL(v->single[window ? 1 : 0][use_dma ? 1 : 0], dim3(grid), dim3(v->WG), v->lds_bytes, stream,
+                       d_stream, nframes, d_twiddles, d_window, d_partial);
+    if (li) {
+        li->grid = grid;
+        li->block = v->WG;
+        li->fpw = v->fpw;
+        li->lds_bytes = v->lds_bytes;
+        li->partial_f32 = v->partial_f32;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fft_accum_hops(int N, int vid, bool window, bool use_dma, const HopArgs& hops,
+                                 const cf* d_twiddles, const float* d_window, double* d_partial, int grid,
+                                 hipStream_t stream, LaunchInfo* li)
+{
+    const Variant* v = find_variant(N, vid);
+    if (!v || grid < 1 || hops.H < 1 || hops.H > kMaxHops || grid > hops.total) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(v->scan[window ? 1 : 0][use_dma ? 1 : 0], dim3(grid), dim3(v->WG), v->lds_bytes, stream,
+                       d_twiddles, d_window, d_partial, hops);
     if (li) {
         li->grid = grid;
         li->block = v->WG;
@@ -808,18 +952,51 @@ hipError_t launch_bluestein(int N, const uint8_t* d_stream, long nframes, const 
     return hipGetLastError();
 }
 
+namespace {
+template <typename PT, int PAIRS, int GROUPS, int UNROLL>
+void launch_reduce_shape(const PT* d_partial, const SlotRanges& slots, int H, int N, double* d_out, bool accumulate,
+                         hipStream_t stream, size_t stride)
+{
+    const dim3 blocks((N + 2 * PAIRS - 1) / (2 * PAIRS), H);
+    hipLaunchKernelGGL((reduce_kernel<PT, PAIRS, GROUPS, UNROLL>), blocks, dim3(PAIRS * GROUPS), 0, stream, d_partial,
+                       slots, N, d_out, accumulate ? 1 : 0, stride);
+}
+}  // namespace
+
+hipError_t launch_reduce_hops(const double* d_partial, const SlotRanges& slots, int H, int N, double* d_out,
+                              bool accumulate, hipStream_t stream, bool partial_f32, size_t slot_stride)
+{
+    if (H < 1 || H > kMaxHops) return hipErrorInvalidValue;
+    const size_t stride = slot_stride ? slot_stride : static_cast<size_t>(N);
+    if (partial_f32) {
+        launch_reduce_shape<float, 8, 32, 8>(reinterpret_cast<const float*>(d_partial), slots, H, N, d_out, accumulate,
+                                             stream, stride);
+        return hipGetLastError();
+    }
+    int shape = 0;
+#ifdef RPF_TUNING
+    if (const char* sh = std::getenv("RPF_TUNE_K3")) shape = std::atoi(sh);     // A/B of the block shapes
+#endif
+    // (measured in situ behind K1, profiles/r03_k3_shapes.txt: all shapes within 0.3 us of each other)
+    switch (shape) {
+    case 1: launch_reduce_shape<double, 8, 32, 8>(d_partial, slots, H, N, d_out, accumulate, stream, stride); break;
+    case 2: launch_reduce_shape<double, 16, 16, 8>(d_partial, slots, H, N, d_out, accumulate, stream, stride); break;
+    case 3: launch_reduce_shape<double, 16, 16, 16>(d_partial, slots, H, N, d_out, accumulate, stream, stride); break;
+    case 4: launch_reduce_shape<double, 8, 16, 16>(d_partial, slots, H, N, d_out, accumulate, stream, stride); break;
+    case 5: launch_reduce_shape<double, 32, 8, 8>(d_partial, slots, H, N, d_out, accumulate, stream, stride); break;
+    case 6: launch_reduce_shape<double, 16, 32, 8>(d_partial, slots, H, N, d_out, accumulate, stream, stride); break;
+    default: launch_reduce_shape<double, 8, 16, 8>(d_partial, slots, H, N, d_out, accumulate, stream, stride); break;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_reduce(const double* d_partial, int nslots, int N, double* d_out,
                          bool accumulate, hipStream_t stream, bool partial_f32, size_t slot_stride)
 {
-    const int blocks = (N + RED_BINS - 1) / RED_BINS;
-    const size_t stride = slot_stride ? slot_stride : static_cast<size_t>(N);
-    if (partial_f32)
-        hipLaunchKernelGGL(reduce_kernel<float>, dim3(blocks), dim3(RED_BINS * RED_GROUPS), 0, stream,
-                           reinterpret_cast<const float*>(d_partial), nslots, N, d_out, accumulate ? 1 : 0, stride);
-    else
-        hipLaunchKernelGGL(reduce_kernel<double>, dim3(blocks), dim3(RED_BINS * RED_GROUPS), 0, stream,
-                           d_partial, nslots, N, d_out, accumulate ? 1 : 0, stride);
-    return hipGetLastError();
+    SlotRanges one;
+    one.begin[0] = 0;
+    for (int h = 1; h <= kMaxHops; ++h) one.begin[h] = nslots;
+    return launch_reduce_hops(d_partial, one, 1, N, d_out, accumulate, stream, partial_f32, slot_stride);
 }
 
 void make_twiddles(int N, std::vector<cf>& out)

@@ -159,6 +159,32 @@ class Datastore:
         self._check(self._lib.rpf_device_reduce(self._handle, ctypes.c_void_p(d_pwr_ptr),
                                                 ctypes.c_void_p(hip_stream)))
 
+    @staticmethod
+    def _hop_arrays(d_stream_ptrs, nbytes, repeats):
+        H = len(d_stream_ptrs)
+        assert len(nbytes) == H and len(repeats) == H
+        return (H, (ctypes.c_void_p * H)(*[int(p) for p in d_stream_ptrs]),
+                (ctypes.c_size_t * H)(*[int(b) for b in nbytes]),
+                (ctypes.c_int64 * H)(*[int(r) for r in repeats]), (ctypes.c_int64 * H)())
+
+    def accumulate_device_hops(self, d_stream_ptrs, nbytes, repeats, d_pwr_ptr, hip_stream=0):
+        """A whole scan of device-resident hops in one call (rpf_accumulate_device_hops): hop h's
+        spectrum lands in d_pwr[h*N : (h+1)*N].  Returns the frames summed per hop."""
+        H, ptrs, nb, rep, done = self._hop_arrays(d_stream_ptrs, nbytes, repeats)
+        self._check(self._lib.rpf_accumulate_device_hops(self._handle, ptrs, nb, rep, H, ctypes.c_void_p(d_pwr_ptr),
+                                                         ctypes.c_void_p(hip_stream), done))
+        return list(done)
+
+    def device_fused_hops(self, d_stream_ptrs, nbytes, repeats, hip_stream=0):
+        """K1 over up to max_hops_per_launch() hops in ONE launch (measurement hook); device_reduce()
+        then writes all their spectra."""
+        H, ptrs, nb, rep, done = self._hop_arrays(d_stream_ptrs, nbytes, repeats)
+        self._check(self._lib.rpf_device_fused_hops(self._handle, ptrs, nb, rep, H, ctypes.c_void_p(hip_stream), done))
+        return list(done)
+
+    def max_hops_per_launch(self):
+        return self._lib.rpf_max_hops_per_launch()
+
     def launch_info(self):
         vals = [ctypes.c_int() for _ in range(4)]
         self._check(self._lib.rpf_last_launch_info(self._handle, *[ctypes.byref(v) for v in vals]))

@@ -391,3 +391,98 @@ extern "C" int rpf_emul_bluestein(int N, const float* window, const uint8_t* str
     }
     return -1;
 }
+
+// ---- hop_partition.h: the host-side partition of a scan's hops over the workgroups of one
+// launch, and the kernel's walk over it restated (same HopCursor, same loop skeleton as
+// fft_accum_kernel) so that the CPU tests can check that every frame of every hop is visited
+// exactly once and that every partial slot is written exactly once.
+#include "../../rtl-power-fftw_amd/csrc/hop_partition.h"
+
+// out_visits[h][f] += 1 for every (hop, frame) a workgroup accumulates; out_slot_hop[slot] = the hop
+// whose partial lands in `slot` (-1: never written; -2: written twice); out_staged[h][f] += 1 for
+// every (hop, frame) staged by slot-0 frame index (what the DMA ring fetched, clamped frames included).
+// Returns the grid, or a negative number on inconsistency.
+extern "C" int rpf_emul_walk_hops(const int64_t* nframes, int H, int fpw, int max_grid, int rawd, int interleave_single,
+                                  int* it_begin, int* slot_begin, int32_t* const* out_visits,
+                                  int* out_slot_hop, int nslots_cap, long* staged_iterations)
+{
+    rpf::HopArgs a;
+    rpf::SlotRanges r;
+    const int grid = rpf::partition_hops(nframes, H, fpw, max_grid, &a, &r, interleave_single != 0);
+    if (grid < 0) return grid;
+    for (int h = 0; h <= H; ++h) {
+        it_begin[h] = a.it_begin[h];
+        slot_begin[h] = r.begin[h];
+    }
+    if (r.begin[H] > nslots_cap) return -10;
+    for (int s = 0; s < nslots_cap; ++s) out_slot_hop[s] = -1;
+    for (int h = 0; h < rpf::kMaxHops; ++h) a.stream[h] = nullptr;
+    *staged_iterations = 0;
+    const rpf::HopArgsView tbl{a};
+    if (a.total != a.it_begin[a.H] || (grid && a.q * grid + a.r != a.total)) return -14;
+    if (grid && a.step != 1 && a.step != grid) return -16;
+    long iterations = 0;
+    for (int w = 0; w < grid; ++w) {
+        int first, count;
+        rpf::hop_share(w, a.q, a.r, a.step, &first, &count);
+        if (count < 1) return -11;                       // the host promises every workgroup an iteration
+        iterations += count;
+        // (the kernel's control flow, statement for statement: rpf_kernels.hip, fft_accum_kernel)
+        const int step = a.step, fstep = fpw * step;
+        rpf::HopCursor ahead;
+        ahead.seek(tbl, first);
+        int ahead_fb = (ahead.j - ahead.begin) * fpw, ahead_fstep = fstep;
+        int ahead_left = count;
+        auto run_length = [&](const rpf::HopCursor& c, int left) {
+            const int in_hop = step == 1 ? c.end - c.j : left;
+            return in_hop < left ? in_hop : left;
+        };
+        int ahead_run = run_length(ahead, ahead_left);
+        ahead_left -= ahead_run;
+        bool parked = false;
+        auto ahead_turn = [&]() {
+            if (ahead_left > 0) {
+                ahead.seek(tbl, ahead.end);
+                ahead_fb = 0;
+                ahead_run = run_length(ahead, ahead_left);
+                ahead_left -= ahead_run;
+            } else {
+                ahead.seek(tbl, 0);
+                ahead_fb = 0;
+                ahead_fstep = 0;
+                ahead_run = 0x7fffffff;
+                parked = true;
+            }
+        };
+        std::vector<std::pair<int, int>> ring(rawd);     // what each ring slot holds: (hop, slot-0 frame); parked: (-1, 0)
+        auto stage_next = [&](int slot) {
+            ring[slot] = parked ? std::make_pair(-1, 0) : std::make_pair(ahead.h, ahead_fb);
+            ++*staged_iterations;
+            ahead_fb += ahead_fstep;
+            if (--ahead_run == 0) ahead_turn();
+        };
+        for (int d = 0; d < rawd; ++d) stage_next(d);
+        rpf::HopCursor cur;
+        cur.seek(tbl, first);
+        int it = 0;
+        while (true) {
+            const int seg = run_length(cur, count - it);
+            if (seg < 1) return -17;
+            int fb = (cur.j - cur.begin) * fpw;
+            for (int n = seg; n > 0; --n, ++it, fb += fstep) {
+                if (ring[it % rawd] != std::make_pair(cur.h, fb)) return -12;   // the ring holds another iteration's bytes
+                if (fb >= cur.nframes) return -18;                             // an iteration without a frame
+                for (int fs = 0; fs < fpw; ++fs)
+                    if (fb + fs < cur.nframes) out_visits[cur.h][fb + fs] += 1;
+                stage_next(it % rawd);
+            }
+            const int slot = a.slot_bias[cur.h] + w;
+            if (slot < r.begin[cur.h] || slot >= r.begin[cur.h + 1]) return -13;
+            out_slot_hop[slot] = out_slot_hop[slot] == -1 ? cur.h : -2;
+            if (it >= count) break;
+            cur.seek(tbl, cur.end);
+        }
+    }
+    if (iterations != a.total) return -15;
+    return grid;
+}

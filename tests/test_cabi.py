@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.lib_path())
     for name in _declared_symbols():
         assert hasattr(lib, name), name
-    assert rpf.load().rpf_abi_version() == 1
+    assert rpf.load().rpf_abi_version() == 2
 
 
 def test_supported_sizes():

@@ -60,7 +60,7 @@ def kernel_bodies(asm):
 
 
 def hottest_loop(lines):
-    """Instructions between the label and the backward branch that span the most instructions."""
+    """Instructions of the per-frame loop (label ... backward branch)."""
     labels, instrs = {}, []
     for line in lines:
         t = line.strip()
@@ -71,14 +71,19 @@ def hottest_loop(lines):
         if not t or t.startswith((";", ".", "//")):
             continue
         instrs.append(t.split(";")[0].strip())
-    best = (0, 0, 0)
+    # the frame loop = the backward branch whose span holds the most packed-f32 arithmetic; among
+    # nested loops with the same arithmetic (the per-hop segment loop encloses the frame loop and adds
+    # only the hand-over) the shortest span
+    best = None
     for idx, ins in enumerate(instrs):
         m = re.match(r"^s_cbranch_\w+\s+(\.LBB\d+_\d+)", ins) or re.match(r"^s_branch\s+(\.LBB\d+_\d+)", ins)
         if m and m.group(1) in labels and labels[m.group(1)] <= idx:
-            span = idx - labels[m.group(1)]
-            if span > best[0]:
-                best = (span, labels[m.group(1)], idx)
-    return instrs[best[1]: best[2] + 1]
+            lo = labels[m.group(1)]
+            pk = sum(1 for i in instrs[lo: idx + 1] if i.startswith("v_pk_"))
+            key = (pk, -(idx - lo))
+            if best is None or key > best[0]:
+                best = (key, lo, idx)
+    return instrs[best[1]: best[2] + 1] if best else []
 
 
 def main():
