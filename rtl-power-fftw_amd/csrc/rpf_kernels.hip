@@ -270,6 +270,206 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
 }
 
 
+// ---- K1 with the first pass on the matrix pipe (N = 4096 = 16 x 256, rectangular window) -----
+// Pass 1 of the decimation-in-frequency transform is Y[r][m] = sum_a x[m + 256 a] W_16^{a r}: a
+// 16-point DFT over a for each of the 256 columns m, on INTEGER data ((v - 127) is exact in f16).
+// In real form that is a 32 x 32 matrix (rows (r, re/im), columns (a, re/im)) times the 32 x 256
+// matrix of samples -- one v_mfma_f32_32x32x16_f16 pair per 32 columns.  The matrix entries
+// (0, +-1, +-sqrt(1/2), +-cos(pi/8), +-sin(pi/8)) are split into three f16 terms hi + mid + lo
+// (33 bits; every f16 x f16 product is exact in the f32 accumulator) that accumulate into the
+// SAME f32 accumulator, scaled by 2^13 so that the lo term stays a normal f16; 2^-13, the
+// (-1)^n of datastore.cxx:73 (= (-1)^m: 256 a is even) and the pass-1 twiddle W_4096^{m r}
+// are one per-lane complex constant per output.  The matrix pipe runs beside the VALU; what
+// the VALU keeps of pass 1 is one v_perm + one v_pk_add_f16 per sample and the twiddles.
+// Lane (l & 31, hh = l >> 5) of wave w (of the frame's four) ends with the outputs
+// r = 4 q + 2 hh + u (q < 4, u < 2) of the columns m = 64 w + 32 cb + (l & 31), cb < 2 -- the
+// MFMA C/D layout, row = (reg & 3) + 8 (reg >> 2) + 4 hh, with the rows ordered (r, re/im) --
+// and stores them where the VALU pass 1 would have: element 256 r + m of the padded slab.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16x __attribute__((ext_vector_type(16)));
+
+__device__ const double kCos16[16] = {
+    1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508978178,
+    0.0, -0.38268343236508978178, -0.70710678118654752440, -0.92387953251128673848,
+    -1.0, -0.92387953251128673848, -0.70710678118654752440, -0.38268343236508978178,
+    0.0, 0.38268343236508978178, 0.70710678118654752440, 0.92387953251128673848};
+
+constexpr int kMfmaScaleLog2 = 13;
+
+// the lane's eight A-operand values of K-step ks, term d (0 hi, 1 mid, 2 lo)
+__device__ __forceinline__ void mfma_a_fragment(int lane, int ks, h8 (&out)[3])
+{
+    const int i = lane & 31, kb = lane >> 5;
+    const int r = 4 * (i >> 3) + 2 * ((i >> 2) & 1) + ((i >> 1) & 1), c_out = i & 1;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int k = 16 * ks + 8 * kb + t, a = k >> 1, c_in = k & 1;
+        const int idx = (a * r) & 15;
+        const double co = kCos16[idx], si = kCos16[(idx + 12) & 15];       // sin(x) = cos(x - pi/2)
+        // Y = (cos - i sin)(xr + i xi): re = cos xr + sin xi, im = -sin xr + cos xi
+        const double m = (c_out == c_in) ? co : (c_out == 0 ? si : -si);
+        double v = m * static_cast<double>(1 << kMfmaScaleLog2);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const _Float16 h = static_cast<_Float16>(static_cast<float>(v));
+            out[d][t] = h;
+            v -= static_cast<double>(static_cast<float>(h));
+        }
+    }
+}
+
+// Measured (profiles/r03_mfma_first_pass.txt): exact to the bar (1.7e-7 from float64 truth, 4.8e-8 from
+// the VALU kernel on config C2) and SLOWER, 65.0 against 53.5 us per C2 launch -- the twelve MFMAs
+// of a wave-frame cost their full 12 x 32 cycles on top of the remaining VALU work wherever they
+// are issued (in order: 65.0; a frame ahead, pinned between the packed-f32 butterflies of passes 2
+// and 3: 69.3; between the f64 accumulate instructions: 64.9): on this part the matrix pipe does not
+// run beside packed-f32 or f64 vector arithmetic, it displaces it.  Kept in the tuning build only.
+template <class G, int WG, int OCC, int RAWD>
+__global__ __launch_bounds__(WG, OCC) void fft_accum_mfma_kernel(const uint8_t* __restrict__ stream,
+                                                                 long nframes,
+                                                                 const cf* __restrict__ twN,
+                                                                 const float* __restrict__ /*window*/,
+                                                                 double* __restrict__ partial)
+{
+    constexpr int P = G::P, T = G::T, N = G::N, NPASS = G::NPASS;
+    constexpr int FPW = WG / T;
+    static_assert(N == 4096 && P == 16 && T == 256 && WG % T == 0 && NPASS == 3, "the 16 x 16 x 16 split of N = 4096");
+    constexpr bool DMA = true, TWLDS = true;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* const slab_base = reinterpret_cast<cf*>(smem);                 // [FPW][LDS_CPX]
+    uint8_t* const raw_base = smem + FPW * G::LDS_CPX * sizeof(cf);    // [WG/64][RAWD][128 P]
+
+    const int tid = threadIdx.x;
+    const int fs = tid / T, t = tid % T;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    constexpr int RAW_SLOT = kRawChunk * P;
+    constexpr int PIECES = P / 8;
+    uint8_t* const wave_raw = raw_base + wave * (RAWD * RAW_SLOT);
+
+    const long stride = static_cast<long>(gridDim.x) * FPW;
+    long fb = static_cast<long>(blockIdx.x) * FPW;
+    if (fb < nframes) {
+#pragma unroll
+        for (int d = 0; d < RAWD; ++d)
+            stage_raw64<G, DMA>(stream, fb + d * stride, nframes, wave_raw + d * RAW_SLOT, wave, lane);
+    }
+
+    // loop-invariant: the matrix (A) fragments, the per-output constants, the later passes' twiddle table
+    h8 amat[2][3];
+    mfma_a_fragment(lane, 0, amat[0]);
+    mfma_a_fragment(lane, 1, amat[1]);
+    const int w4 = wave & 3, ml = lane & 31, hh = lane >> 5;
+    cf tw1[2][8];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+        for (int reg = 0; reg < 8; ++reg) {
+            const int m = 64 * w4 + 32 * cb + ml, r = 4 * (reg >> 1) + 2 * hh + (reg & 1);
+            const float sc = ((m & 1) ? -1.0f : 1.0f) / static_cast<float>(1 << kMfmaScaleLog2);
+            tw1[cb][reg] = twN[m * r] * sc;
+        }
+    }
+    cf tw[NPASS - 1][P - 1];                                           // (pass >= 2: in the LDS table)
+    cf* const twtable = reinterpret_cast<cf*>(raw_base + (WG / 64) * RAWD * RAW_SLOT);
+    fill_twlds<G, 1>(tid, WG, twN, twtable);
+    exchange_sync<true>();
+    double acc[P];
+#pragma unroll
+    for (int a = 0; a < P; ++a) acc[a] = 0.0;
+    // this lane's pass-1 outputs in the slab: element 256 r + m -> slot 272 r + m + m / 16
+    const int store_slot = G::slot(256 * (2 * hh) + 64 * w4 + ml);
+    cf* const slab = slab_base + fs * G::LDS_CPX;
+
+    PhaseClock clk;
+    clk.start();
+    for (int it = 0; fb < nframes; fb += stride, ++it) {
+        const bool active = (fb + fs) < nframes;
+        uint8_t* const ring_slot = wave_raw + (it % RAWD) * RAW_SLOT;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RAWD - 1) * PIECES) : "memory");
+        exchange_sync<false>();
+        // B operand: sample a = 8 ks + 4 hh + j of column 32 cb + ml sits at byte 128 a + 2 (32 cb + ml) of the
+        // wave's raw slot; (I, Q) -> (1024 + I, 1024 + Q) as two f16 by one v_perm, minus 1151 -> (v - 127)
+        // exactly (datastore.cxx:75)
+        const uint8_t* const lane_raw = ring_slot + 2 * ml + 512 * hh;
+        h8 bmat[2][2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t iq = *reinterpret_cast<const uint16_t*>(lane_raw + kRawChunk * (8 * ks + j) + 64 * cb);
+                    const uint32_t bits = __builtin_amdgcn_perm(0x64646464u, iq, 0x04010400u);
+                    const h2 v = __builtin_bit_cast(h2, bits) - h2{(_Float16)1151.0f, (_Float16)1151.0f};
+                    bmat[cb][ks][2 * j] = v.x;
+                    bmat[cb][ks][2 * j + 1] = v.y;
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot's reads have returned
+        exchange_sync<false>();
+        stage_raw64<G, DMA>(stream, fb + RAWD * stride, nframes, ring_slot, wave, lane);
+
+        f16x y[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) y[cb][k] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+                    y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(amat[ks][d], bmat[cb][ks], y[cb], 0, 0, 0);
+
+        // y = 2^13 x the first pass: twiddle, sign, scale -> the slab
+        cf x[P];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int reg = 0; reg < 8; ++reg) {
+                const int v = 4 * (reg >> 1) + 2 * (reg & 1);
+                x[8 * cb + reg] = cmul(cf{y[cb][v], y[cb][v + 1]}, tw1[cb][reg]);
+            }
+        exchange_sync<true>();                                   // every wave is done with the previous frame's slab
+        {
+            cf* const p = slab + store_slot;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int reg = 0; reg < 8; ++reg) p[34 * cb + 272 * (4 * (reg >> 1) + (reg & 1))] = x[8 * cb + reg];
+        }
+        exchange_sync<true>();
+        middle_passes<G, 2, 0, TWLDS>(t, x, tw, slab, clk, twtable);
+        phase_fetch<G, NPASS>(t, x, slab);
+        phase_last<G>(x);
+        if (active) phase_accumulate(x, acc, P);
+    }
+    clk.publish(lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    exchange_sync<true>();
+    double* const stage = reinterpret_cast<double*>(smem);
+    constexpr int SN = N + N / 16;
+#pragma unroll
+    for (int a = 0; a < P; ++a) {
+        const int bin = bin_of<G>(t, a);
+        stage[fs * SN + bin + (bin >> 4)] = acc[a];
+    }
+    exchange_sync<true>();
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    for (int bin = 2 * tid; bin < N; bin += 2 * WG) {
+        d2 v = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < FPW; ++k) {
+            v.x += stage[k * SN + bin + (bin >> 4)];
+            v.y += stage[k * SN + bin + 1 + (bin >> 4)];
+        }
+        *reinterpret_cast<d2*>(partial + static_cast<size_t>(blockIdx.x) * N + bin) = v;
+    }
+}
+
 // ---- K1, a scan of several acquisitions per launch -----------------------------------------
 __device__ __forceinline__ void write_lane(int& v, int uniform_value, int lane_const)
 {
@@ -732,6 +932,16 @@ Variant make_variant(int vid)
                      fft_accum_scan_kernel<G, WG, OCCW, true, true, DBUF, ACCB, PF32, RAWD, ABL, TWLDS>}}};
 }
 
+// the matrix-pipe first pass (N = 4096, rectangular window, LDS-DMA staging only; the other three
+// table entries keep the VALU kernel so that a windowed or misaligned launch still runs)
+template <int N, int P, int OCC, int WG, int RAWD>
+Variant make_mfma_variant(int vid)
+{
+    Variant v = make_variant<N, P, OCC, OCC, false, 0, false, RAWD, 0, true, WG>(vid);
+    v.single[0][1] = fft_accum_mfma_kernel<Geom<N, P>, WG, OCC, RAWD>;
+    return v;
+}
+
 const Variant kVariants[] = {
     // defaults.  Template arguments after <N, P>: OCC, OCCW, DBUF, ACCB, PF32, RAWD, ABL, TWLDS, WGO
     // 128 = 16 x 8 and 256 = 16 x 16: two passes and ONE exchange at 16 points per lane (measured
@@ -770,6 +980,7 @@ const Variant kVariants[] = {
     make_variant<4096, 16, 2, 2, false, 0, false, 2, 0, false, 512>(53),
     make_variant<4096, 16, 2, 2, false, 0, false, 4, 0, false, 512>(54),
     make_variant<2048, 16, 2, 2, false, 0, false, 4, 0, true, 512>(51),
+    make_mfma_variant<4096, 16, 2, 512, 2>(60),              // first pass on the matrix pipe (exact, slower: see the kernel)
     make_variant<512, 8, 4, 4, false, 0, false, 4>(1),  make_variant<512, 8, 4, 4, false, 0, false, 8>(2),
     make_variant<512, 16, 3, 3, false, 0, false, 2>(3),
     make_variant<128, 8, 4, 4, false, 0, false, 4>(3),   make_variant<256, 8, 4, 4, false, 0, false, 4>(3),    // 8 points per lane, three passes
