@@ -56,11 +56,11 @@ typedef struct rpf_config {
 #define RPF_FLAG_NONE 0u
 /* Stage raw bytes through VGPRs instead of LDS-DMA (debug / A-B measurement). */
 #define RPF_FLAG_NO_LDS_DMA 1u
-/* Sizes 16384..262144: use the fused persistent four-step kernel (the intermediate stays in the
- * XCDs' L2, teams of workgroups synchronised through per-XCD counters) instead of the two-kernel
- * path (intermediate through HBM).  Exact and parity-tested, but measured SLOWER than the
- * two-kernel path so far, hence opt-in; the engine falls back by itself where the
- * kernel's teams cannot assemble. */
+/* Sizes 16384..262144, TUNING BUILD ONLY (the shipped library fails rpf_engine_create with
+ * RPF_ERR_INVALID_ARGUMENT, like RPF_FLAG_VARIANT(k != 0)): the fused persistent four-step kernel
+ * (the intermediate stays in the XCDs' L2) instead of the two-kernel path.  Exact and parity-tested,
+ * measured slower; a launch whose workgroup teams do not assemble NaN-fills the
+ * spectrum and rpf_finish reports RPF_ERR_HARDWARE. */
 #define RPF_FLAG_FOURSTEP_FUSED 2u
 /* Sizes served by the LDS mixed-radix kernels (500, 1000, 3000 ... 80000; 16384, 32768): use the
  * kernel they would get without them -- Bluestein, resp. the four-step pair for 16384 and 32768

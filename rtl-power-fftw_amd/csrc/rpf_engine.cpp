@@ -398,6 +398,15 @@ void worker_main(rpf_engine* e)
     recycle();
 
     WORKER_TRY(hipStreamSynchronize(e->compute_stream), "hipStreamSynchronize");
+    if (e->fused && ok()) {
+        // a fused launch whose teams did not assemble has NaN-filled the spectrum: that is an error, not a result
+        bool aborted = false;
+        WORKER_TRY(rpf::fourstep_fused_aborted(e->d_fused_ctl, e->compute_stream, &aborted), "fourstep_fused_aborted");
+        if (ok() && aborted) {
+            e->worker_rc = RPF_ERR_HARDWARE;
+            e->worker_error = "the fused four-step kernel's workgroup teams did not assemble (device busy?)";
+        }
+    }
     for (auto& s : e->staging) s.in_flight = false;
     WORKER_TRY(hipMemcpy(e->pwr.data(), e->d_pwr, sizeof(double) * e->N, hipMemcpyDeviceToHost), "hipMemcpy(pwr)");
     e->repeats_done = frames_issued;
@@ -452,6 +461,11 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT,
                     "Number of bins must be a positive even number.");
     const int variant = static_cast<int>((cfg->flags >> 8) & 0xffu);
+#ifndef RPF_TUNING
+    if (cfg->flags & RPF_FLAG_FOURSTEP_FUSED)
+        return fail(nullptr, RPF_ERR_INVALID_ARGUMENT,
+                    "RPF_FLAG_FOURSTEP_FUSED: the fused four-step kernel exists only in the tuning build of this library.");
+#endif
     // (asking for the fused four-step kernel is asking for the four-step path)
     const bool mixed = rpf::mixed_supported(cfg->N, variant) &&
                        !(cfg->flags & (RPF_FLAG_NO_MIXED_RADIX | RPF_FLAG_FOURSTEP_FUSED));
@@ -632,6 +646,10 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         // stream); if they do not, this engine uses the two-kernel path.
         const size_t round_bytes = 2u * 262144u * 8u;         // FR frames of N samples for each of 8 teams
         void* d_dummy = nullptr;
+        struct FreeOnExit {                                   // (every exit of this block, CREATE_TRY's included)
+            void*& p;
+            ~FreeOnExit() { if (p) (void)hipFree(p); }
+        } free_dummy{d_dummy};
         CREATE_TRY(hipMalloc(&d_dummy, round_bytes));
         CREATE_TRY(hipMemset(d_dummy, 0x80, round_bytes));
         bool aborted = true;
@@ -640,7 +658,6 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
                                                      e->d_tw_sub, e->d_tw_sub2, e->d_twiddles, e->d_window, e->d_scratch,
                                                      e->d_partial, e->d_fused_ctl, e->compute_stream);
         if (lerr == hipSuccess) lerr = rpf::fourstep_fused_aborted(e->d_fused_ctl, e->compute_stream, &aborted);
-        (void)hipFree(d_dummy);
         if (lerr != hipSuccess || aborted) {
             (void)hipGetLastError();
             e->fused = false;

@@ -260,6 +260,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_rows_kernel(const cf* __restr
 }
 
 
+#ifdef RPF_TUNING   // the fused persistent four-step kernel: exact, measured slower -- lab equipment
 // ---- fused four-step: the intermediate never leaves the XCD's L2 ----------------------------
 // K2a/K2b above exchange Y through HBM: 8 B written + 8 B read per sample against 2 algorithmic
 // bytes, and the pair runs at the speed of that traffic.  Here ONE persistent kernel does both
@@ -604,6 +605,8 @@ namespace rpf {
 namespace {
 #endif
 
+#endif  // RPF_TUNING
+
 // Large Bluestein path: even N in (4096, 131072] that is not a power of two,
 // M = M1 x M2 = 2^ceil(log2(2N-1)) (bluestein_tables.h has the identity):
 //   K2a (BLU)  a = (v - 127) g zero-padded to M; columns of FFT_M #1 -> Y[f][n2][k1]
@@ -717,7 +720,9 @@ using ColsFn = void (*)(const uint8_t*, int, const cf*, const cf*, const float*,
 using MidFn = void (*)(const cf*, int, const cf*, const cf*, const cf*, cf*);
 using RowsFn = void (*)(const cf*, int, const cf*, double*, int);
 
+#ifdef RPF_TUNING
 using FusedFn = void (*)(const uint8_t*, int, const cf*, const cf*, const cf*, const float*, cf*, double*, FusedCtl*);
+#endif
 using RowsTableFn = void (*)(const cf*, size_t, size_t, int, std::vector<cf>&);
 using ColsTableFn = void (*)(const cf*, int, std::vector<cf>&);
 
@@ -726,10 +731,13 @@ struct SplitInfo {
     ColsFn cols[2][2];   // [window][dma]
     RowsFn rows;
     RowsTableFn step_twiddles;   // W_N^{n2 k1} in K2a's lane order
+#ifdef RPF_TUNING
     FusedFn fused[2][2];         // [window][dma]
     int fused_lds, fused_fr;     // LDS bytes; frames per team round
+#endif
 };
 
+#ifdef RPF_TUNING
 template <class S>
 constexpr int fused_lds_bytes()
 {
@@ -738,6 +746,7 @@ constexpr int fused_lds_bytes()
     constexpr int tile = S::N2 * S::ROW_PITCH * (int)sizeof(cf);
     return slab + tile + raw;
 }
+#endif
 
 template <int N1, int N2>
 SplitInfo make_split()
@@ -747,9 +756,12 @@ SplitInfo make_split()
                      {{fourstep_cols_kernel<S, false, false>, fourstep_cols_kernel<S, false, true>},
                       {fourstep_cols_kernel<S, true, false>, fourstep_cols_kernel<S, true, true>}},
                      fourstep_rows_kernel<S>, lane_ordered_rows<typename S::GA>,
+#ifdef RPF_TUNING
                      {{fourstep_fused_kernel<S, false, false>, fourstep_fused_kernel<S, false, true>},
                       {fourstep_fused_kernel<S, true, false>, fourstep_fused_kernel<S, true, true>}},
-                     fused_lds_bytes<S>(), 262144 / S::N};
+                     fused_lds_bytes<S>(), 262144 / S::N
+#endif
+    };
 }
 
 const SplitInfo kSplits[] = {
@@ -896,6 +908,7 @@ hipError_t launch_fourstep(int N, bool window, bool use_dma, const uint8_t* d_st
     return hipSuccess;
 }
 
+#ifdef RPF_TUNING
 // ---- fused four-step -----------------------------------------------------------
 size_t fourstep_fused_scratch_bytes(int N)       // Y of one round per XCD: 8 x 2 MB
 {
@@ -966,6 +979,20 @@ hipError_t fourstep_fused_aborted(const void* d_ctl, hipStream_t stream, bool* a
     *aborted = h.abort[0] != 0;
     return hipSuccess;
 }
+
+#else   // the shipped library has no fused kernel: asking for it fails rpf_engine_create
+size_t fourstep_fused_scratch_bytes(int) { return 0; }
+int fourstep_fused_slots(int) { return 0; }
+size_t fourstep_fused_ctl_bytes() { return 0; }
+hipError_t fourstep_fused_prepare(int, int, int*) { return hipErrorNotSupported; }
+hipError_t launch_fourstep_fused(int, bool, bool, const uint8_t*, long, const cf*, const cf*, const cf*, const float*, cf*,
+                                 double*, void*, hipStream_t)
+{
+    return hipErrorNotSupported;
+}
+hipError_t launch_fused_poison(const void*, double*, int, hipStream_t) { return hipErrorNotSupported; }
+hipError_t fourstep_fused_aborted(const void*, hipStream_t, bool*) { return hipErrorNotSupported; }
+#endif
 
 // ---- large Bluestein path --------------------------------------------------
 bool bigblu_supported(int N) { return find_blu_split(N) != nullptr; }

@@ -12,6 +12,7 @@
 // ranges of a hop otherwise); the main thread adds a hop's per-device accumulators
 // in device order (fixed order: reproducible) and writes the spectra in hop order,
 // so stdout is what one device would have printed.
+#include <atomic>
 #include <condition_variable>
 #include <ctime>
 #include <fstream>
@@ -143,12 +144,25 @@ public:
         std::string error;
         ReturnValue error_code = ReturnValue::Success;
         std::vector<std::thread> workers;
+        std::atomic<bool> cancel(false);       // a worker failed or the pass was cut short: start no further job
+        // whatever leaves this scope -- the return at the end or an exception in between -- joins the workers first
+        struct JoinAll {
+            std::vector<std::thread>& threads;
+            std::atomic<bool>& cancel;
+            ~JoinAll()
+            {
+                cancel.store(true);
+                for (std::thread& w : threads)
+                    if (w.joinable()) w.join();
+            }
+        } join_all{workers, cancel};
         finished_workers_ = 0;
         for (int d = 0; d < G; ++d)
             workers.emplace_back([&, d]() {
                 ScanMetadata unused;
                 try {
                     for (const DeviceJob& j : jobs[d]) {
+                        if (cancel.load()) break;
                         Acquisition acq(options_, aux_, *sources_[d], *stores_[d], unused, rate_, freqs[j.hop], j.shard);
                         acq.run();
                         std::lock_guard<std::mutex> lock(mutex);
@@ -171,6 +185,7 @@ public:
                         const RPFexception* r = dynamic_cast<const RPFexception*>(&e);
                         error_code = r ? r->returnValue() : ReturnValue::AcquisitionError;
                     }
+                    cancel.store(true);
                     progress.notify_all();
                 }
                 std::lock_guard<std::mutex> lock(mutex);
@@ -252,6 +267,7 @@ public:
                 }
             if (checkInterrupt(InterruptState::FinishNow)) complete = false;
         }
+        if (!complete) cancel.store(true);
         for (std::thread& w : workers) w.join();
         if (!error.empty()) throw RPFexception(error, error_code);
         pass_base_ += static_cast<uint64_t>(H) * bytes_per_hop_;
@@ -370,7 +386,8 @@ int run(int argc, char** argv)
                     // the reference would divide by zero here and print a spectrum of NaNs (acquisition.cxx:393)
                     std::cerr << "No complete spectrum at " << acquisition.tuned_freq()
                               << " Hz; nothing written." << std::endl;
-                    if (source->exhausted()) break;
+                    // (a second Ctrl-C must end the scan here too, not retune once per remaining hop)
+                    if (source->exhausted() || checkInterrupt(InterruptState::FinishNow)) break;
                     continue;
                 }
                 if (options.matrixMode && meta_pending) {

@@ -198,7 +198,9 @@ def test_c4_full_size_on_its_own_stream(c4):
     # every bin that is not one of the 16 deterministic lines: the plain bar, vs truth and vs the CPU path
     assert e_gpu["floor"] < PARITY and vs_oracle_floor < PARITY
     assert e_gpu["total"] < 3e-7
-    # the lines: the bar, or -- where float32 itself gives out -- not behind the other float32 FFTs
+    # the lines against the CPU path -- north_star's bar, asserted (DESIGN.md 6 quotes the measured 4.8e-7) ...
+    assert vs_oracle_lines < PARITY
+    # ... and against float64 truth: the bar, or -- where float32 itself gives out -- not behind the other float32 FFTs
     assert e_gpu["lines"] < max(PARITY, 1.25 * max(e_orc["lines"], e_roc["lines"]))
 
 

@@ -44,8 +44,8 @@ while time.time() - t0 < budget:
         N = int(rng.choice(POW2))
     elif fam < 5:
         N = int(rng.choice(FOUR))
-        if rng.integers(0, 2):
-            flags = rpf._lib.FLAG_FOURSTEP_FUSED          # the fused persistent kernel (teams, barriers)
+        if rng.integers(0, 2) and "tuning" in os.path.basename(rpf._lib.lib_path()):
+            flags = rpf._lib.FLAG_FOURSTEP_FUSED          # the fused persistent kernel (tuning build only)
     elif fam < 7:
         N = 2 * int(rng.integers(1, 2049))
     elif fam < 9:
