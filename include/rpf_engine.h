@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RPF_ABI_VERSION 2   /* 2: rpf_accumulate_device_hops, rpf_device_fused_hops */
+#define RPF_ABI_VERSION 2   /* 2: rpf_accumulate_device_hops, rpf_device_fused_hops, rpf_scan_reducer_* */
 
 /* Return codes = ReturnValue of /root/reference/src/exceptions.h:25-34. */
 #define RPF_OK 0
@@ -62,9 +62,10 @@ typedef struct rpf_config {
  * measured slower; a launch whose workgroup teams do not assemble NaN-fills the
  * spectrum and rpf_finish reports RPF_ERR_HARDWARE. */
 #define RPF_FLAG_FOURSTEP_FUSED 2u
-/* Sizes served by the LDS mixed-radix kernels (500, 1000, 3000 ... 80000; 16384, 32768): use the
- * kernel they would get without them -- Bluestein, resp. the four-step pair for 16384 and 32768
- * (A/B measurement; all are exact to the float32 bar). */
+/* Sizes served by the LDS mixed-radix kernels (the tables csrc/mixed_plans.inc and
+ * csrc/mixed_plans_split.inc: 500, 1000, 3000 ... 80000; 16384, 32768): use the kernel they would
+ * get without them -- Bluestein, resp. the four-step pair for 16384 and 32768 (A/B measurement;
+ * all are exact to the float32 bar). */
 #define RPF_FLAG_NO_MIXED_RADIX 4u
 /* Tuning: select kernel variant k for this N.  The shipped library contains only
  * variant 0 (one kernel per N x {window} x {staging}); any other k makes
@@ -162,6 +163,27 @@ int rpf_accumulate_device_hops(rpf_engine* e, const void* const* d_streams, cons
 int rpf_device_fused_hops(rpf_engine* e, const void* const* d_streams, const size_t* nbytes,
                           const int64_t* repeats, int n_hops, void* hip_stream, int64_t* repeats_done);
 int rpf_max_hops_per_launch(void);
+
+/* Datastore::pwr as it sits in HBM after rpf_finish: copied (device to device, or peer to peer when
+ * dst_device is another device) into d_dst[N]; synchronises hip_stream before returning. */
+int rpf_copy_power_device(const rpf_engine* e, double* d_dst, void* hip_stream, int dst_device);
+
+/* ---- multi-GPU scans in one process: the final reduce over RCCL / xGMI ----------------
+ * One engine per device runs its share of a scan's hops (hop-major, frame-aligned); a scan reducer owns
+ * one RCCL communicator over those devices (ncclCommInitAll; librccl.so is loaded with dlopen) and, on
+ * every device, a block of max_hops x N doubles.  Per pass: _begin zeroes the blocks; after an engine's
+ * rpf_finish, _deposit copies its accumulator into row `hop` of its device's block; _reduce issues ONE
+ * ncclReduce(sum, ncclDouble, hops x N) onto the first device and one device-to-host copy.
+ * rpf_scan_reducer_create fails with RPF_ERR_HARDWARE when RCCL is missing or refuses the device list
+ * (e.g. one device listed twice); callers then add the per-device spectra on the host, which gives the
+ * same sums up to the order of the additions. */
+typedef struct rpf_scan_reducer rpf_scan_reducer;
+int rpf_scan_reducer_create(const int* devices, int n_devices, int N, int max_hops, rpf_scan_reducer** out);
+void rpf_scan_reducer_destroy(rpf_scan_reducer* r);
+const char* rpf_scan_reducer_last_error(const rpf_scan_reducer* r);
+int rpf_scan_reducer_begin(rpf_scan_reducer* r);
+int rpf_scan_reducer_deposit(rpf_scan_reducer* r, int slot, int hop, const rpf_engine* e);
+int rpf_scan_reducer_reduce(rpf_scan_reducer* r, int hops, double* host_out /* hops x N */);
 
 /* Launch geometry of the last fused-kernel launch (for DESIGN/bench reporting):
  * workgroups, threads per workgroup, frames per workgroup, LDS bytes. */

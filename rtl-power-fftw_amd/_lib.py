@@ -78,6 +78,14 @@ _SYMBOLS = [
                                              ctypes.POINTER(ctypes.c_int64), ctypes.c_int, _P,
                                              ctypes.POINTER(ctypes.c_int64)]),
     ("rpf_max_hops_per_launch", ctypes.c_int, []),
+    ("rpf_copy_power_device", ctypes.c_int, [_P, _P, _P, ctypes.c_int]),
+    ("rpf_scan_reducer_create", ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.POINTER(_P)]),
+    ("rpf_scan_reducer_destroy", None, [_P]),
+    ("rpf_scan_reducer_last_error", ctypes.c_char_p, [_P]),
+    ("rpf_scan_reducer_begin", ctypes.c_int, [_P]),
+    ("rpf_scan_reducer_deposit", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P]),
+    ("rpf_scan_reducer_reduce", ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     ("rpf_last_launch_info", ctypes.c_int, [_P] + [ctypes.POINTER(ctypes.c_int)] * 4),
 ]
 

@@ -813,6 +813,23 @@ int rpf_get_power(const rpf_engine* e, double* out)
     return RPF_OK;
 }
 
+int rpf_copy_power_device(const rpf_engine* e, double* d_dst, void* hip_stream, int dst_device)
+{
+    if (!e || !d_dst) return RPF_ERR_INVALID_ARGUMENT;
+    rpf_engine* me = const_cast<rpf_engine*>(e);
+    if (e->worker_running)
+        return fail(me, RPF_ERR_INVALID_ARGUMENT, "rpf_copy_power_device: acquisition still running (call rpf_finish first)");
+    DeviceScope on_device(e->device);
+    HIP_TRY(me, on_device.status());
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (dst_device == e->device)
+        HIP_TRY(me, hipMemcpyAsync(d_dst, e->d_pwr, sizeof(double) * e->N, hipMemcpyDeviceToDevice, s));
+    else
+        HIP_TRY(me, hipMemcpyPeerAsync(d_dst, dst_device, e->d_pwr, e->device, sizeof(double) * e->N, s));
+    HIP_TRY(me, hipStreamSynchronize(s));
+    return RPF_OK;
+}
+
 int64_t rpf_get_repeats_done(const rpf_engine* e) { return e ? e->repeats_done : 0; }
 
 int rpf_get_histogram(const rpf_engine* e, int* out)
@@ -821,6 +838,28 @@ int rpf_get_histogram(const rpf_engine* e, int* out)
     std::lock_guard<std::mutex> lock(const_cast<rpf_engine*>(e)->status_mutex);
     std::memcpy(out, e->queue_histogram.data(), sizeof(int) * e->queue_histogram.size());
     return RPF_OK;
+}
+
+// The producer side of rpf_accumulate: pageable stream -> pinned hand-off buffer.  One thread copies
+// ~10 GB/s, a fifth of what the H2D link behind it takes, so a large buffer is filled by several threads
+// (measured with 5 x 105 MB buffers: 8.0 -> see bench.py's end_to_end; small buffers are not worth a fork).
+static void fill_buffer(uint8_t* dst, const uint8_t* src, size_t n)
+{
+    constexpr size_t kPiece = 4u << 20;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t want = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 8), n / kPiece);
+    if (want < 2) {
+        std::memcpy(dst, src, n);
+        return;
+    }
+    std::vector<std::thread> helpers;
+    const size_t share = (n / want + 63) & ~static_cast<size_t>(63);
+    for (size_t t = 1; t < want; ++t) {
+        const size_t lo = t * share, hi = std::min(n, lo + share);
+        if (lo < hi) helpers.emplace_back([=]() { std::memcpy(dst + lo, src + lo, hi - lo); });
+    }
+    std::memcpy(dst, src, std::min(n, share));
+    for (std::thread& h : helpers) h.join();
 }
 
 int rpf_accumulate(rpf_engine* e, const uint8_t* stream, size_t nbytes, int64_t repeats,
@@ -840,7 +879,7 @@ int rpf_accumulate(rpf_engine* e, const uint8_t* stream, size_t nbytes, int64_t 
             rpf_buffer_unget(e, buf);
             break;
         }
-        std::memcpy(buf, stream + pos, n);
+        fill_buffer(buf, stream + pos, n);
         rc = rpf_buffer_submit(e, buf, n);
         if (rc != RPF_OK) break;
         pos += n;

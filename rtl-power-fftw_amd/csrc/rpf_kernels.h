@@ -52,8 +52,9 @@ hipError_t launch_reduce(const double* d_partial, int nslots, int N, double* d_o
 hipError_t launch_reduce_hops(const double* d_partial, const SlotRanges& slots, int H, int N, double* d_out,
                               bool accumulate, hipStream_t stream, bool partial_f32 = false, size_t slot_stride = 0);
 
-// ---- mixed-radix path (KM, rpf_mixed.hip): even N with prime factors 2, 3, 5 only, not a power of two: the planned
-// kernel for the sizes of mixed_plans.inc (up to 10000), the Stockham kernel for the rest up to 5120 --
+// ---- mixed-radix path (KM, rpf_mixed.hip): the planned kernel for the sizes of mixed_plans.inc, its split form
+// for those of mixed_plans_split.inc (the two tables are the list of sizes), the run-time Stockham kernel for every
+// other even N <= 5120 with prime factors 2, 3, 5 only --
 // variant: 0 = the shipped kernel of the size; others (tuning build only) = alternative plans
 bool mixed_supported(int N, int variant = 0);
 hipError_t plan_mixed(int N, int variant, bool windowed, int device, LaunchInfo* li);

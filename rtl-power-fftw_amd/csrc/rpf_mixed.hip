@@ -372,8 +372,8 @@ __global__ __launch_bounds__(PL::WG) void mixed_plan_kernel(const uint8_t* __res
 // pass of a decimation-in-frequency transform, evaluated for one output only, so nothing but the raw
 // bytes ever crosses workgroups -- the P workgroups of a frame read the same 2N bytes (L2 / Infinity
 // Cache serve the repeats) where the four-step kernels move 16 bytes of intermediate per sample.
-// P = 2 ... 5 costs 5 P extra instructions per point; the sizes between 20000 and 80000 bins that
-// large Bluestein served at 0.04 Tsample/s.
+// P = 2 ... 5 costs 5 P extra instructions per point.  Which sizes run this way is the table in
+// mixed_plans_split.inc (20000 ... 80000 bins and 32768; large Bluestein served them at 0.04 Tsample/s).
 // sections J, J + 1, ... of the frame: while section J is unpacked and added to v, section J + 1 is in flight
 // into the other raw buffer (and, after the last one, section 0 of the workgroup's next frame)
 template <class PL, int P, bool WINDOW, int J, class Load>
@@ -572,10 +572,13 @@ int lds_bytes(int N)       // [frame slots][2 buffers + accumulators] + the twid
 
 }  // namespace
 
-// even N whose frame fits one workgroup's LDS: a planned kernel for the sizes in kPlans (up to 16000
-// bins, and 16384 -- the one power of two K1 cannot hold and the four-step kernels serve at half the
-// rate), the Stockham kernel for the other sizes with only prime factors 2, 3, 5 up to 5120 bins.  variant != 0 (tuning build): another plan of the same size; 100 = the
-// Stockham kernel for a size that has a plan.
+// Even N served from one workgroup's LDS.  The single source of truth for WHICH sizes is the pair of
+// tables the library is compiled from: mixed_plans.inc (the planned kernel: round sizes with small prime
+// factors up to 16000 bins, and 16384 -- the one power of two K1 cannot hold and the four-step kernels
+// serve at half the rate) and mixed_plans_split.inc (the split form N = P x M, 20000 ... 80000 and 32768);
+// the run-time Stockham kernel takes every other even size up to 5120 bins with prime factors 2, 3, 5 only.
+// variant != 0 (tuning build): another plan of the same size; 100 = the Stockham kernel for a size that
+// has a plan.
 #ifdef RPF_TUNING
 constexpr int kStockhamVariant = 100;
 #endif
@@ -610,7 +613,14 @@ hipError_t plan_mixed(int N, int variant, bool windowed, int device, LaunchInfo*
     hipDeviceProp_t prop;
     if ((err = hipGetDeviceProperties(&prop, device)) != hipSuccess) return err;
     li->grid = std::max(per_cu, 1) * prop.multiProcessorCount;
-    if (pe) li->grid -= li->grid % (pe->split > 1 ? 8 * pe->split : 1);        // (split form: see its XCD mapping)
+    if (pe && pe->split > 1) {
+        // split form: whole rounds of the 8 XCDs (its XCD-local mapping) where the device has that many
+        // resident workgroups, else any multiple of the split factor; a device too small for even one
+        // group gets no plan, and rpf_engine_create takes the next kernel family
+        const int unit = li->grid >= 8 * pe->split ? 8 * pe->split : pe->split;
+        li->grid -= li->grid % unit;
+        if (li->grid < pe->split) return hipErrorInvalidValue;
+    }
     li->block = wg;
     li->fpw = pe ? pe->fpw : kMixedWG / threads_per_frame(N);
     li->lds_bytes = lds;

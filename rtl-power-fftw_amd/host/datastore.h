@@ -121,6 +121,8 @@ public:
     check(rpf_finish(engine_, &repeats_done));
     check(rpf_get_power(engine_, pwr.data()));
   }
+  // the engine behind this Datastore (multi-device scans hand it to the scan reducer)
+  const rpf_engine* engine() const { return engine_; }
   // datastore.cxx:98-103
   void printQueueHistogram() const {
     std::vector<int> h(params.buffers + 1);

@@ -55,6 +55,7 @@ const Spec kSpecs[] = {
     {0, "synthetic", Kind::Int64, "seed", "Use the built-in synthetic receiver instead of a dongle."},
     {0, "gpu", Kind::Int, "ordinal", "HIP device to run on."},
     {0, "gpus", Kind::Text, "a,b,...", "HIP devices to spread a scan over (one engine per listed device)."},
+    {0, "reduce", Kind::Text, "rccl|host", "With --gpus: where a scan's per-device spectra are added (default: rccl if it loads, else host)."},
     {'h', "help", Kind::Flag, "", "Displays usage information and exits."},
     {0, "version", Kind::Flag, "", "Displays version information and exits."},
 };
@@ -208,6 +209,11 @@ Options parse_command_line(int argc, const char* const* argv)
         o.device = o.devices.front();
     } else {
         o.devices.push_back(o.device);
+    }
+    if (p.has("reduce")) {
+        o.reduce = p.get("reduce");
+        if (o.reduce != "rccl" && o.reduce != "host")
+            throw RPFexception("Argument to --reduce must be rccl or host. Exiting.", ReturnValue::InvalidArgument);
     }
 
     if (o.buf_length % base_buf != 0) {                              // params.cxx:171-175

@@ -51,6 +51,7 @@ struct Options : Params {
     bool synthetic = false;          // --synthetic given
     uint64_t synthetic_seed = 2;
     std::vector<int> devices;        // --gpus a,b,... (else the single --gpu ordinal)
+    std::string reduce;              // --reduce rccl|host ("" = rccl if it loads, else host)
     bool show_help = false, show_version = false;
 };
 

@@ -12,6 +12,7 @@
 // ranges of a hop otherwise); the main thread adds a hop's per-device accumulators
 // in device order (fixed order: reproducible) and writes the spectra in hop order,
 // so stdout is what one device would have printed.
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <ctime>
@@ -121,6 +122,30 @@ public:
         }
         bytes_per_hop_ = replay_bytes_per_hop(options);
     }
+    ~MultiDeviceScan() { rpf_scan_reducer_destroy(reducer_); }
+
+    // north_star / SURVEY.md 8e: the per-device accumulators of a pass meet in ONE RCCL reduce onto the
+    // first device (rpf_scan_reducer_*: ncclCommInitAll over the listed devices, librccl loaded with
+    // dlopen).  Without RCCL, or with a device list it refuses (the same device twice), the main thread
+    // adds them itself in device order -- the same sums up to the order of the additions.
+    void prepare_reduce(int max_hops)
+    {
+        if (options_.reduce == "host" || reducer_ || reducer_tried_) return;
+        reducer_tried_ = true;
+        int rc = rpf_scan_reducer_create(options_.devices.data(), static_cast<int>(options_.devices.size()), options_.N,
+                                         max_hops, &reducer_);
+        if (rc != RPF_OK) {
+            reducer_ = nullptr;
+            if (options_.reduce == "rccl")
+                throw RPFexception(std::string("--reduce rccl: ") + rpf_scan_reducer_last_error(nullptr), (ReturnValue)rc);
+            if (chatty(options_))
+                std::cerr << "RCCL reduce not available (" << rpf_scan_reducer_last_error(nullptr)
+                          << "); adding the per-device spectra on the host." << std::endl;
+        } else if (chatty(options_)) {
+            std::cerr << "Per-device spectra are reduced over RCCL onto gpu " << options_.devices.front() << "." << std::endl;
+        }
+        reducer_hops_ = max_hops;
+    }
 
     // One pass over `freqs`; spectra to stdout / the matrix file in hop order.  Returns
     // false when the pass was cut short (interrupt, exhausted replay).
@@ -138,6 +163,12 @@ public:
                 j.shard.hop_base = pass_base_ + static_cast<uint64_t>(j.hop) * bytes_per_hop_;
                 parts[j.hop][j.part].device_slot = d;
             }
+
+        prepare_reduce(H);
+        const bool rccl = reducer_ && H <= reducer_hops_;
+        if (rccl && rpf_scan_reducer_begin(reducer_) != RPF_OK)
+            throw RPFexception(rpf_scan_reducer_last_error(reducer_), ReturnValue::HardwareError);
+        std::vector<double> reduced;                 // rccl: hops x N, filled once every worker has finished
 
         std::mutex mutex;
         std::condition_variable progress;
@@ -165,9 +196,12 @@ public:
                         if (cancel.load()) break;
                         Acquisition acq(options_, aux_, *sources_[d], *stores_[d], unused, rate_, freqs[j.hop], j.shard);
                         acq.run();
+                        if (rccl && stores_[d]->repeats_done > 0 &&
+                            rpf_scan_reducer_deposit(reducer_, d, j.hop, stores_[d]->engine()) != RPF_OK)
+                            throw RPFexception(rpf_scan_reducer_last_error(reducer_), ReturnValue::HardwareError);
                         std::lock_guard<std::mutex> lock(mutex);
                         HopPart& p = parts[j.hop][j.part];
-                        p.pwr = stores_[d]->pwr;
+                        if (!rccl) p.pwr = stores_[d]->pwr;
                         p.repeats_done = stores_[d]->repeats_done;
                         p.device_readouts = acq.device_readouts();
                         p.successful_readouts = acq.successful_readouts();
@@ -200,6 +234,18 @@ public:
             meta.firstAcqTimestamp = Acquisition::utc_now();
             meta.cntTimeStamps++;
         }
+        if (rccl) {
+            // the reduce needs every device's block: wait for the workers, then ONE ncclReduce + one D2H
+            {
+                std::unique_lock<std::mutex> lock(mutex);
+                progress.wait(lock, [&]() { return finished_workers_ == G; });
+            }
+            if (error.empty()) {
+                reduced.assign(static_cast<size_t>(H) * options_.N, 0.0);
+                if (rpf_scan_reducer_reduce(reducer_, H, reduced.data()) != RPF_OK)
+                    throw RPFexception(rpf_scan_reducer_last_error(reducer_), ReturnValue::HardwareError);
+            }
+        }
         for (int h = 0; h < H && complete; ++h) {
             {
                 std::unique_lock<std::mutex> lock(mutex);
@@ -217,8 +263,11 @@ public:
             // the hop's accumulator: per-device partial sums added in device order
             std::vector<double> pwr(options_.N, 0.0);
             int64_t repeats_done = 0, readouts = 0, successful = 0;
+            if (rccl) std::copy(reduced.begin() + static_cast<size_t>(h) * options_.N,
+                                reduced.begin() + static_cast<size_t>(h + 1) * options_.N, pwr.begin());
             for (const HopPart& p : parts[h]) {
-                for (int i = 0; i < options_.N; ++i) pwr[i] += p.pwr[i];
+                if (!rccl)
+                    for (int i = 0; i < options_.N; ++i) pwr[i] += p.pwr[i];
                 repeats_done += p.repeats_done;
                 readouts += p.device_readouts;
                 successful += p.successful_readouts;
@@ -287,6 +336,9 @@ private:
     std::vector<std::unique_ptr<Datastore>> stores_;
     uint64_t bytes_per_hop_ = 0, pass_base_ = 0;
     int finished_workers_ = 0;
+    rpf_scan_reducer* reducer_ = nullptr;
+    bool reducer_tried_ = false;
+    int reducer_hops_ = 0;
     bool exhausted_ = false;
     int64_t hops_written_ = 0;
 };

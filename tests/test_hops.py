@@ -197,3 +197,37 @@ def test_c5_scan_in_one_launch_matches_the_fixtures(torch_dev):
     got = d_out.cpu().numpy()
     worst = max(max_rel(got[h], gs[h]["pwr"]) for h in range(8))
     assert worst < 1e-6, worst
+
+
+@pytest.mark.gpu
+def test_scan_reducer_over_rccl_with_one_device(torch_dev):
+    """rpf_scan_reducer_* (the product's final reduce) with the one device this box has:
+    RCCL loads (dlopen), ncclCommInitAll / ncclReduce run with a single rank, and the block that comes
+    back holds exactly what the engines deposited -- rows of hops nobody deposited stay zero."""
+    N, R, H = 4096, 40, 3
+    lib = rpf.load()
+    devs = (ctypes.c_int * 1)(0)
+    red = ctypes.c_void_p()
+    rc = lib.rpf_scan_reducer_create(devs, 1, N, H, ctypes.byref(red))
+    assert rc == 0, lib.rpf_scan_reducer_last_error(None)
+    try:
+        want = {}
+        assert lib.rpf_scan_reducer_begin(red) == 0
+        with rpf.Datastore(rpf.Params(N=N, repeats=R)) as ds:
+            for hop in (2, 0):                                       # hop 1 is "another device's"
+                pwr, done = ds.accumulate(rpf.synth.noise_tones_iq(60 + hop, N * R), R)
+                assert done == R
+                want[hop] = pwr
+                assert lib.rpf_scan_reducer_deposit(red, 0, hop, ds._handle) == 0
+        out = np.full((H, N), np.nan)
+        assert lib.rpf_scan_reducer_reduce(red, H, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) == 0
+        assert np.array_equal(out[0], want[0]) and np.array_equal(out[2], want[2]) and np.all(out[1] == 0.0)
+        # argument errors are reported, not executed
+        assert lib.rpf_scan_reducer_deposit(red, 1, 0, ds._handle) == 3
+        assert lib.rpf_scan_reducer_reduce(red, H + 1, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) == 3
+    finally:
+        lib.rpf_scan_reducer_destroy(red)
+    # a device listed twice is something RCCL refuses: create fails with the hardware code, nothing leaks
+    two = (ctypes.c_int * 2)(0, 0)
+    rc = lib.rpf_scan_reducer_create(two, 2, N, H, ctypes.byref(red))
+    assert rc == 7 and not red.value

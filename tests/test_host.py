@@ -401,6 +401,12 @@ def test_cli_scan_spread_over_several_engines(host, tmp_path):
         if la != lb:                                 # a last-digit difference of the 6-digit dB value
             fa, fb = la.split(), lb.split()
             assert fa[0] == fb[0] and abs(float(fa[1]) - float(fb[1])) <= 2e-5 * abs(float(fa[1]))
+    # where the per-device spectra are added: RCCL refuses one device listed twice, so these runs fell back to the
+    # host (that is the default's contract); asking for RCCL explicitly must then fail loudly, --reduce host must not
+    forced = subprocess.run([CLI] + scan + ["--gpus", "0,0", "--reduce", "rccl"], capture_output=True, text=True)
+    assert forced.returncode == 7 and "--reduce rccl" in forced.stderr, forced.stderr
+    on_host = subprocess.run([CLI] + scan + ["--gpus", "0,0", "--reduce", "host"], capture_output=True, text=True)
+    assert on_host.returncode == 0 and _data_lines(on_host.stdout) == _data_lines(one.stdout)
     # a single hop over two engines: frame ranges of the one hop, summed
     single = ["-f", "433920000", "-b", "1024", "-n", "300", "--synthetic", "3", "-q"]
     s1 = subprocess.run([CLI] + single, capture_output=True, text=True)
