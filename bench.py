@@ -376,6 +376,7 @@ def main():
 
     events = []
     regions = []
+    my_regions = []
     last_blk = 0
     while True:
         t0 = time.perf_counter()
@@ -387,6 +388,7 @@ def main():
             last_blk = step(i, ev)
         fence(args.steps - 1)
         elapsed = time.perf_counter() - t0
+        my_regions.append(elapsed)
         if use_dist:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -433,12 +435,25 @@ def main():
             del all_hops
         dist.barrier()
 
+    # every rank's own view of the timed region (so that a multi-GPU run explains itself): its wall time
+    # for the K steps, its fused-kernel bracket, what it processed
+    k1_all = [a.elapsed_time(b) for a, b in events]
+    mine_report = {"rank": rank, "device": torch.cuda.get_device_name(dev), "region_s_median": float(np.median(my_regions)),
+                   "kernel_ms_median": float(np.median(k1_all)) if k1_all else None,
+                   "frames_per_step": sum(m[2] for m in mine) if strong else mine[0][2],
+                   "hops_per_step": len(mine) if strong else 1,
+                   "reduce_wait_s_per_step": ring.wait_seconds / max(1, ring.waits) if use_dist else None}
+    per_rank = [mine_report]
+    if use_dist and world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine_report)
+        per_rank = gathered
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         samples_per_step = hops * R * N if strong else world * N * R
         value = samples_per_step * args.steps / elapsed
         # median of the in-region brackets (a stray preemption in one bracket must not move the figure); mean beside it
-        k1_all = [a.elapsed_time(b) for a, b in events]
         k1_ms = float(np.median(k1_all)) if events else None
         k1_mean_ms = float(np.mean(k1_all)) if events else None
         # one launch of the dominant kernel: one acquisition (C2-C4), the rank's hops of the scan (C5)
@@ -497,6 +512,8 @@ def main():
                        "min_region_s": min(regions), "max_region_s": max(regions)},
             "roofline": roof,
         }
+        if use_dist:
+            out["per_rank"] = per_rank
         if check:
             out["check"] = check
         if one_gpu:

@@ -61,6 +61,8 @@ class ScanRing:
         self.dst = dst
         self.enabled = enabled
         self.clear_on_reuse = clear_on_reuse
+        self.wait_seconds = 0.0        # host time spent waiting for a block's previous reduce (bench.py reports it)
+        self.waits = 0
 
     def __len__(self):
         return len(self.blocks)
@@ -68,7 +70,11 @@ class ScanRing:
     def begin(self, k):
         """Block k is about to be written for a new scan."""
         if self.pending[k] is not None:
+            import time
+            t0 = time.perf_counter()
             self.pending[k].wait()
+            self.wait_seconds += time.perf_counter() - t0
+            self.waits += 1
             self.pending[k] = None
         if self.enabled and self.clear_on_reuse and self.used[k]:
             import torch.distributed as dist
