@@ -93,25 +93,31 @@ def cpu_baseline(N, R, stream, pwr_gpu, window=None):
             break
     one = N * R * passes / dt
     rel = float(np.max(np.abs(pwr_gpu - pwr) / pwr))
-    # all host cores (disjoint frame ranges; not the reference's structure)
+    # all host cores (disjoint frame ranges; not the reference's structure): one persistent worker (plan)
+    # per thread, every thread walks its frames `loops` times -- thread start-up and planning are not what
+    # is being compared with the GPU
     cores = os.cpu_count() or 1
+    lib.rpf_oracle_accumulate_mt_loops.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_float), u8p, ctypes.c_size_t,
+                                                   ctypes.c_int64, ctypes.c_int, ctypes.c_int, dp,
+                                                   ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]
     pwr_mt = np.zeros(N)
-    t0 = time.perf_counter()
-    p2 = 0
+    secs = ctypes.c_double()
+    loops = 1
     while True:
-        rc = lib.rpf_oracle_accumulate_mt(N, wp, stream.ctypes.data_as(u8p), stream.size,
-                                          R, cores, pwr_mt.ctypes.data_as(dp), ctypes.byref(done))
+        rc = lib.rpf_oracle_accumulate_mt_loops(N, wp, stream.ctypes.data_as(u8p), stream.size, R, cores, loops,
+                                                pwr_mt.ctypes.data_as(dp), ctypes.byref(done), ctypes.byref(secs))
         assert rc == 0
-        p2 += 1
-        dt2 = time.perf_counter() - t0
-        if dt2 >= CPU_BASELINE_SECONDS / 2:
+        if secs.value >= CPU_BASELINE_SECONDS / 4 or loops >= 1 << 14:
             break
-    allc = N * R * p2 / dt2
+        loops = int(min(1 << 14, max(2 * loops, loops * CPU_BASELINE_SECONDS / 3 / max(secs.value, 1e-4))))
+    allc = N * R * loops / secs.value
+    assert float(np.max(np.abs(pwr_mt - pwr) / pwr)) < 1e-12      # the same frames, another grouping of the sums
     out = {
         "value": one, "unit": "samples/s", "cores": 1, "kind": "port",
         "sample": "the step's stream (%d frames x %d bins) replayed %d times through oracle/rpf_oracle.c, "
                   "1 thread like the reference's single FFT thread" % (R, N, passes),
         "all_cores_value": allc, "all_cores": cores,
+        "all_cores_sample": "%d threads, one persistent plan each, %d walks over the step's stream" % (cores, loops),
         "gpu_vs_cpu_max_rel_err": rel,
     }
     # real FFTW (the reference's FFT, datastore.cxx:30-33,82), if this box has it: first 400 frames
@@ -125,6 +131,14 @@ def cpu_baseline(N, R, stream, pwr_gpu, window=None):
         out["fftw"] = fftw_probe.report(N, head_bytes, head, {"oracle": o_head}, window)
     except Exception as exc:          # the probe must never take the benchmark down
         out["fftw"] = {"fftw": "probe failed: %r" % (exc,)}
+    # a third float32 FFT of independent provenance on every box: Intel MKL's DFTI (torch.fft on CPU tensors;
+    # MKL also ships the FFTW3 interface a reference build can link instead of libfftw3f)
+    try:
+        from oracle import mkl_probe
+        head = min(R, 400)
+        out["mkl"] = mkl_probe.report(N, stream[: 2 * N * head], head, {"oracle": o_head, "gpu_first_frames": None}, window)
+    except Exception as exc:
+        out["mkl"] = {"mkl": "probe failed: %r" % (exc,)}
     return out
 
 

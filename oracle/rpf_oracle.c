@@ -10,6 +10,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -277,6 +278,79 @@ int rpf_oracle_accumulate_mt(int N, const float* window, const uint8_t* stream, 
         for (int t = 0; t < nthreads; ++t) s += partial[(size_t)t * (size_t)N + i];
         pwr_out[i] = s;
     }
+    if (repeats_done_out) *repeats_done_out = frames;
+    free(jobs); free(th); free(partial);
+    return rc;
+}
+
+/* The all-cores TIMING leg of bench.py's cpu_baseline: like rpf_oracle_accumulate_mt, but every thread keeps
+ * ONE worker (its plan and long-double twiddle tables are built once, outside what is worth timing) and walks
+ * its frame range `loops` times, so that thread start-up and planning do not dominate the figure printed
+ * beside the GPU's.  pwr_out = the sum over one walk (as rpf_oracle_accumulate_mt). */
+typedef struct {
+    rpf_oracle_worker* w;
+    const uint8_t* stream;
+    int N;
+    int64_t first, count;
+    int loops;
+    double* pwr;
+    int rc;
+} mtl_job;
+
+static void* mtl_run(void* arg)
+{
+    mtl_job* j = (mtl_job*)arg;
+    for (int l = 0; l < j->loops; ++l) {
+        rpf_oracle_worker_begin(j->w, j->count);
+        rpf_oracle_worker_consume(j->w, j->stream + 2 * (size_t)j->N * (size_t)j->first, 2 * (size_t)j->N * (size_t)j->count);
+        if (rpf_oracle_worker_repeats_done(j->w) != j->count) j->rc = -2;
+    }
+    const double* p = rpf_oracle_worker_pwr(j->w);
+    for (int i = 0; i < j->N; ++i) j->pwr[i] = p[i];
+    return NULL;
+}
+
+int rpf_oracle_accumulate_mt_loops(int N, const float* window, const uint8_t* stream, size_t nbytes,
+                                   int64_t repeats, int nthreads, int loops, double* pwr_out,
+                                   int64_t* repeats_done_out, double* seconds_in_threads)
+{
+    if (N < 2 || nthreads < 1 || loops < 1) return -1;
+    int64_t frames = (int64_t)(nbytes / (2 * (size_t)N));
+    if (frames > repeats) frames = repeats;
+    if (nthreads > frames) nthreads = frames > 0 ? (int)frames : 1;
+    mtl_job* jobs = (mtl_job*)calloc((size_t)nthreads, sizeof(mtl_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
+    double* partial = (double*)calloc((size_t)nthreads * (size_t)N, sizeof(double));
+    if (!jobs || !th || !partial) { free(jobs); free(th); free(partial); return -1; }
+    int rc = 0;
+    for (int t = 0; t < nthreads; ++t) {          /* planning: not timed */
+        jobs[t].w = rpf_oracle_worker_create(N, window, 32);
+        if (!jobs[t].w) rc = -1;
+        jobs[t].stream = stream;
+        jobs[t].N = N;
+        jobs[t].first = frames * t / nthreads;
+        jobs[t].count = frames * (t + 1) / nthreads - jobs[t].first;
+        jobs[t].loops = loops;
+        jobs[t].pwr = partial + (size_t)t * (size_t)N;
+    }
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    if (rc == 0) {
+        for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, mtl_run, &jobs[t]);
+        for (int t = 0; t < nthreads; ++t) {
+            pthread_join(th[t], NULL);
+            if (jobs[t].rc) rc = jobs[t].rc;
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (seconds_in_threads) *seconds_in_threads = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    for (int i = 0; i < N; ++i) {
+        double s = 0;
+        for (int t = 0; t < nthreads; ++t) s += partial[(size_t)t * (size_t)N + i];
+        pwr_out[i] = s;
+    }
+    for (int t = 0; t < nthreads; ++t)
+        if (jobs[t].w) rpf_oracle_worker_destroy(jobs[t].w);
     if (repeats_done_out) *repeats_done_out = frames;
     free(jobs); free(th); free(partial);
     return rc;

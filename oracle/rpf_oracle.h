@@ -68,6 +68,11 @@ int rpf_oracle_accumulate(int N, const float* window, int precision,
 int rpf_oracle_accumulate_mt(int N, const float* window, const uint8_t* stream, size_t nbytes,
                              int64_t repeats, int nthreads, double* pwr_out,
                              int64_t* repeats_done_out);
+/* The same, timing-friendly: one persistent worker (plan) per thread, `loops` walks over its frame range;
+ * *seconds_in_threads = wall time from the first thread's start to the last one's end (planning excluded). */
+int rpf_oracle_accumulate_mt_loops(int N, const float* window, const uint8_t* stream, size_t nbytes,
+                                   int64_t repeats, int nthreads, int loops, double* pwr_out,
+                                   int64_t* repeats_done_out, double* seconds_in_threads);
 
 /* ---- Output stage: Acquisition::write_data, text mode ----
  * /root/reference/src/acquisition.cxx:360-433.  Mutates pwr[N/2] (DC

@@ -473,3 +473,23 @@ def test_real_fftw_if_this_box_has_it(torch_dev):
         print("real FFTW, N=%d R=%d: %s" % (N, R, rep))
         for flag in ("measure", "estimate"):
             assert rep[flag]["max_rel_vs_gpu"] < PARITY and rep[flag]["max_rel_vs_oracle"] < PARITY
+
+
+def test_gpu_against_mkl_the_third_float32_fft(torch_dev):
+    """The GPU against Intel MKL's float32 FFT (oracle/mkl_probe.py: the reference's loop around torch.fft on CPU
+    tensors) on C1 and the first 400 frames of C2 and C3 -- an industrial float32 FFT that, unlike FFTW, exists on
+    every box; the same bar as against the CPU oracle."""
+    import sys
+    from helpers import ROOT
+    sys.path.insert(0, ROOT)
+    from oracle import mkl_probe
+    if not mkl_probe.available():
+        pytest.skip("this torch build has no MKL")
+    for N, R, stream, w in ((512, 100, rpf.synth.uniform_iq(1, 512 * 100), None),
+                            (4096, 400, rpf.synth.noise_tones_iq(2, 4096 * 400), None),
+                            (4096, 400, rpf.synth.noise_tones_iq(2, 4096 * 400), rpf.synth.hann_window(4096))):
+        with rpf.Datastore(rpf.Params(N=N, window=w is not None, repeats=R), w) as ds:
+            got, _ = run_device(ds, stream, R, torch_dev)
+        rep = mkl_probe.report(N, stream, R, {"gpu": got}, w)
+        print("MKL, N=%d R=%d window=%s: %s" % (N, R, w is not None, rep))
+        assert rep["max_rel_vs_gpu"] < PARITY, rep

@@ -302,3 +302,18 @@ def test_fftw_probe_pins_the_oracle_when_the_real_library_exists():
     for r in (rep, rep2):
         for flag in ("measure", "estimate"):
             assert r[flag]["max_rel_vs_oracle"] < 1e-6, r
+
+
+def test_oracle_against_mkl_the_third_float32_fft():
+    """A float32 FFT of independent provenance that IS on every box: Intel MKL's DFTI through torch.fft on
+    CPU tensors (oracle/mkl_probe.py: the reference's loop, datastore.cxx:66-89, around it).  The oracle must
+    agree with it to the parity bar on the configurations' streams -- C1, and the first frames of C2 / C3."""
+    from oracle import mkl_probe
+    if not mkl_probe.available():
+        pytest.skip("this torch build has no MKL")
+    for N, R, stream, w in ((512, 100, rpf.synth.uniform_iq(1, 512 * 100), None),
+                            (4096, 400, rpf.synth.noise_tones_iq(2, 4096 * 400), None),
+                            (4096, 400, rpf.synth.noise_tones_iq(2, 4096 * 400), rpf.synth.hann_window(4096))):
+        rep = mkl_probe.report(N, stream, R, {"oracle": oracle_accumulate(N, stream, R, w)[0]}, w)
+        assert rep["mkl"] == "present" and rep["frames"] == R
+        assert rep["max_rel_vs_oracle"] < 1e-6, rep
