@@ -96,7 +96,15 @@ def cpu_baseline(N, R, stream, pwr_gpu, window=None):
     # all host cores (disjoint frame ranges; not the reference's structure): one persistent worker (plan)
     # per thread, every thread walks its frames `loops` times -- thread start-up and planning are not what
     # is being compared with the GPU
-    cores = os.cpu_count() or 1
+    # (the cores this process may run on: affinity mask and cgroup CPU quota -- a container's share, not the
+    # machine's nameplate; the GPU boxes show 256 CPUs and grant 16)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(math.ceil(int(quota) / int(period)))))
+    except Exception:
+        pass
     lib.rpf_oracle_accumulate_mt_loops.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_float), u8p, ctypes.c_size_t,
                                                    ctypes.c_int64, ctypes.c_int, ctypes.c_int, dp,
                                                    ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]
@@ -116,7 +124,7 @@ def cpu_baseline(N, R, stream, pwr_gpu, window=None):
         "value": one, "unit": "samples/s", "cores": 1, "kind": "port",
         "sample": "the step's stream (%d frames x %d bins) replayed %d times through oracle/rpf_oracle.c, "
                   "1 thread like the reference's single FFT thread" % (R, N, passes),
-        "all_cores_value": allc, "all_cores": cores,
+        "all_cores_value": allc, "all_cores": cores, "machine_cpus": os.cpu_count(),
         "all_cores_sample": "%d threads, one persistent plan each, %d walks over the step's stream" % (cores, loops),
         "gpu_vs_cpu_max_rel_err": rel,
     }

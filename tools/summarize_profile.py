@@ -26,7 +26,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
@@ -42,17 +42,21 @@ def copy(path, name):
         shutil.copy(path, os.path.join(dst, name))
 
 
-for name in ("bench.json", "bench_20steps.json", "c3_bench.json", "c4_bench.json", "c5_bench.json"):
+for name in ("bench.json", "bench_20steps.json", "c3_bench.json", "c4_bench.json", "c5_bench.json", "c5_rccl_bench.json",
+             "c5_shard8_bench.json"):
     copy(os.path.join(src, name), tag + "_" + name)
 copy(find("c2_trace", "c2_kernel_stats.csv"), tag + "_kernel_stats.csv")
 copy(find("c3_trace", "c3_kernel_stats.csv"), tag + "_c3_kernel_stats.csv")
 copy(find("c4_trace", "c4_kernel_stats.csv"), tag + "_c4_kernel_stats.csv")
-for name in ("hbm_read.txt", "lds_valu.txt", "k1_fixed_cost.txt", "sizes.txt"):
+copy(find("c5_trace", "c5_kernel_stats.csv"), tag + "_c5_kernel_stats.csv")
+for name in ("hbm_read.txt", "lds_valu.txt", "k1_fixed_cost.txt", "sizes.txt", "mfma_valu.txt"):
     copy(os.path.join(src, name), tag + "_" + name)
 captured = open(os.path.join(src, "captured.txt")).read().strip() if os.path.exists(os.path.join(src, "captured.txt")) else None
 
 
 def classify(name):
+    if "fft_accum_scan_kernel" in name:
+        return "K1_scan"
     if "fft_accum_kernel" in name:
         return "K1_fft_accum"
     if "reduce_kernel" in name:
@@ -111,6 +115,19 @@ for cfg in ("c2", "c3"):
     if "FETCH_SIZE" in k1 and "WRITE_SIZE" in k1:
         traffic["fft_accum_%s_hbm_bytes_per_launch" % cfg] = (traffic["fft_accum_%s_fetch_bytes_per_launch" % cfg] +
                                                               traffic["fft_accum_%s_write_bytes_per_launch" % cfg])
+
+# C5: one launch of the scan kernel = the 8 hops x 5000 frames of a scan
+c5 = {}
+for sub in ("c5_pmc_FETCH_SIZE", "c5_pmc_WRITE_SIZE"):
+    m, _ = means(rows_of(sub, "c5"), full_grid_only=False)
+    for k, d in m.items():
+        c5.setdefault(k, {}).update(d)
+out["C5_scan"] = c5
+ks = c5.get("K1_scan", {})
+if "FETCH_SIZE" in ks and "WRITE_SIZE" in ks:
+    traffic["fft_accum_c5_fetch_bytes_per_launch"] = ks["FETCH_SIZE"] * 1024.0 * 2.0
+    traffic["fft_accum_c5_write_bytes_per_launch"] = ks["WRITE_SIZE"] * 1024.0
+    traffic["fft_accum_c5_hbm_bytes_per_launch"] = ks["FETCH_SIZE"] * 1024.0 * 2.0 + ks["WRITE_SIZE"] * 1024.0
 
 # C4: one acquisition = 8 batches of the column and row kernels
 c4 = {}
