@@ -25,8 +25,10 @@
 //
 // HBM/L2 traffic per sample: 2 B raw (algorithmic) + 8 B Y written + 8 B Y read
 // + 8 B of W_N twiddles (L2-resident table); frames are processed in batches of
-// 256 MB of Y (measured: 64 MB batches 13 % slower, 128 MB 2 % slower -- launch
-// tails, not Infinity-Cache residency, decide).
+// 2 GB of Y -- 1024 frames at N = 262144, i.e. config C4's whole acquisition in ONE launch pair
+// (round 3; 288 GB of HBM are there to be used).  Measured: 256 MB batches 1.19 ms per C4
+// acquisition, 2 GB 1.03 ms; round 1: 64 MB batches 13 % slower than 256 MB, 128 MB 2 % -- launch
+// tails and K2b's partial-spectrum round trip per launch decide, not Infinity-Cache residency.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -43,7 +45,7 @@ struct __attribute__((aligned(16))) cf4 { cf lo, hi; };   // two neighbouring co
 constexpr int kWG = 1024, kWaves = kWG / 64;
 constexpr int kColTile = 64;          // columns per K2a tile (128 raw bytes per row)
 constexpr int kRowDwords = 33;        // 32 data dwords + 1 pad per staged raw row
-constexpr size_t kScratchBytes = 256u << 20;
+constexpr size_t kScratchBytes = static_cast<size_t>(2048) << 20;      // of intermediate per launch pair
 
 // Everything that depends on the factorisation N = N1 * N2.
 template <int N1_, int N2_>
@@ -167,21 +169,28 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_cols_kernel(const uint8_t* __
             exchange_sync<false>();
             // 16 bytes per lane and store: 8-byte stores are issue-bound at ~7 B/clk/CU
             // (MI355X_MICROARCH.md, store tail), which is what K2a ran at
-            cf* const yrow = Y + (static_cast<size_t>(f) * N2 + c) * N1;
+            // Layout of the intermediate.  Four-step: tile-major, Y[f][k1 / ROW_TILE][n2][k1 % ROW_TILE] -- the
+            // [N2][ROW_TILE] tile K2b loads is then ONE contiguous run (64 KB at 512 x 512) instead of N2 lines
+            // 8 N1 bytes apart, and what a K2a workgroup adds to a tile is kColTile consecutive lines.  The large
+            // Bluestein path keeps Y[f][n2][k1] (its consumer, bluestein_mid_kernel, walks whole rows).
+            cf* const yrow = BLU ? Y + (static_cast<size_t>(f) * N2 + c) * N1
+                                 : Y + static_cast<size_t>(f) * S::N + static_cast<size_t>(c) * S::ROW_TILE;
 #pragma unroll
             for (int a = 0; a < G::P / 2; ++a) {
                 const int e = 2 * t + 2 * T * a;
                 cf4 v;
                 v.lo = slab[G::slot(e)];
                 v.hi = slab[G::slot(e + 1)];
-                *reinterpret_cast<cf4*>(yrow + e) = v;
+                if constexpr (BLU) *reinterpret_cast<cf4*>(yrow + e) = v;
+                else *reinterpret_cast<cf4*>(yrow + static_cast<size_t>(e / S::ROW_TILE) * (N2 * S::ROW_TILE) + e % S::ROW_TILE) = v;
             }
             exchange_sync<false>();
         }
     }
 }
 
-template <class S>
+// TILED: the intermediate is tile-major (K2a's four-step layout above); else Y[f][n2][k1] (large Bluestein).
+template <class S, bool TILED>
 __global__ __launch_bounds__(kWG, 4) void fourstep_rows_kernel(const cf* __restrict__ Y, int nframes,
                                                               const cf* __restrict__ tw_sub,
                                                               double* __restrict__ partial, int first)
@@ -213,11 +222,12 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_rows_kernel(const cf* __restr
     constexpr int HALF = S::ROW_TILE / 2;
     cf4 nxt[PER];
     auto fetch = [&](int f) {
-        const cf* const yf = Y + static_cast<size_t>(f) * S::N + S::ROW_TILE * ktile;
+        const cf* const yf = Y + static_cast<size_t>(f) * S::N + (TILED ? static_cast<size_t>(N2) * S::ROW_TILE : S::ROW_TILE) * ktile;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int idx = i * kWG + tid;
-            nxt[i] = *reinterpret_cast<const cf4*>(yf + static_cast<size_t>(idx / HALF) * N1 + 2 * (idx % HALF));
+            if constexpr (TILED) nxt[i] = *reinterpret_cast<const cf4*>(yf + 2 * idx);
+            else nxt[i] = *reinterpret_cast<const cf4*>(yf + static_cast<size_t>(idx / HALF) * N1 + 2 * (idx % HALF));
         }
     };
     if (fg < nframes) fetch(fg);
@@ -755,7 +765,7 @@ SplitInfo make_split()
     return SplitInfo{S::N, N1, N2, S::COLS_LDS, S::ROWS_LDS, S::BATCH, S::GROUPS, S::ROW_TILES,
                      {{fourstep_cols_kernel<S, false, false>, fourstep_cols_kernel<S, false, true>},
                       {fourstep_cols_kernel<S, true, false>, fourstep_cols_kernel<S, true, true>}},
-                     fourstep_rows_kernel<S>, lane_ordered_rows<typename S::GA>,
+                     fourstep_rows_kernel<S, true>, lane_ordered_rows<typename S::GA>,
 #ifdef RPF_TUNING
                      {{fourstep_fused_kernel<S, false, false>, fourstep_fused_kernel<S, false, true>},
                       {fourstep_fused_kernel<S, true, false>, fourstep_fused_kernel<S, true, true>}},
@@ -798,7 +808,7 @@ BluSplitInfo make_blu_split()
     return BluSplitInfo{S::N, M1, M2, S::COLS_LDS, S::ROWS_LDS, SR::ROWS_LDS, S::BATCH, SR::GROUPS,
                         SR::ROW_TILES, S::ROW_TILES,
                         {fourstep_cols_kernel<S, false, false, true>, fourstep_cols_kernel<S, false, true, true>},
-                        bluestein_mid_kernel<S>, fourstep_rows_kernel<SR>, lane_ordered_rows<typename S::GA>,
+                        bluestein_mid_kernel<S>, fourstep_rows_kernel<SR, false>, lane_ordered_rows<typename S::GA>,
                         lane_ordered_rows<typename S::GB>, lane_ordered_cols<typename S::GB>};
 }
 

@@ -72,7 +72,7 @@ hipError_t launch_bluestein(int N, const uint8_t* d_stream, long nframes, const 
 
 // ---- four-step path (rpf_fourstep.hip): N = N1 x N2, powers of two 16384..262144 --
 bool fourstep_supported(int N);
-size_t fourstep_scratch_bytes(int N);  // intermediate Y[batch][N2][N1] complex floats (256 MB)
+size_t fourstep_scratch_bytes(int N);  // the intermediate of one launch pair: 2 GB of complex floats, tile-major (rpf_fourstep.hip)
 int fourstep_partial_slots(int N);     // partial spectra written by K2b (frame groups)
 int fourstep_sub_lengths(int N, int* n1, int* n2);
 // Host tables in the kernels' lane order: step_tw[n2][.] = W_N^{n2 k1} (N entries),
@@ -102,7 +102,7 @@ hipError_t fourstep_fused_aborted(const void* d_ctl, hipStream_t stream, bool* a
 // ---- large Bluestein path (rpf_fourstep.hip): even N in (4096, 131072], not a power of two --
 bool bigblu_supported(int N);
 int bigblu_lengths(int N, int* M, int* m1, int* m2);   // M = m1 * m2 = 2^ceil(log2(2N-1))
-size_t bigblu_scratch_bytes(int N);    // two intermediates of 256 MB
+size_t bigblu_scratch_bytes(int N);    // two intermediates of 2 GB
 int bigblu_partial_slots(int N);       // partial spectra of M (not N) doubles each
 hipError_t bigblu_prepare(int N, int device, LaunchInfo* li);
 // Host tables (each M entries, in the kernels' lane order) from bluestein_tables.h's g (N) and bhat (M).
