@@ -129,7 +129,9 @@ if "FETCH_SIZE" in ks and "WRITE_SIZE" in ks:
     traffic["fft_accum_c5_write_bytes_per_launch"] = ks["WRITE_SIZE"] * 1024.0
     traffic["fft_accum_c5_hbm_bytes_per_launch"] = ks["FETCH_SIZE"] * 1024.0 * 2.0 + ks["WRITE_SIZE"] * 1024.0
 
-# C4: one acquisition = 8 batches of the column and row kernels
+# C4: one acquisition = ONE launch of the column kernel and one of the row kernel (round 3: 2 GB of intermediate;
+# rounds 1-2: 8 batches of 128 frames)
+C4_BATCHES = 1.0
 c4 = {}
 for sub in ("c4_pmc_FETCH_SIZE", "c4_pmc_WRITE_SIZE"):
     m, tot = means(rows_of(sub, "c4"), full_grid_only=False)
@@ -140,14 +142,14 @@ for sub in ("c4_pmc_FETCH_SIZE", "c4_pmc_WRITE_SIZE"):
             c4.setdefault(k + "_totals", {})[c] = {"sum_KiB": s, "launches": n}
 out["C4_fourstep"] = c4
 try:
-    acq = c4["K2b_rows_totals"]["FETCH_SIZE"]["launches"] / 8.0
+    acq = c4["K2b_rows_totals"]["FETCH_SIZE"]["launches"] / C4_BATCHES
     fetch = (c4["K2a_cols_totals"]["FETCH_SIZE"]["sum_KiB"] + c4["K2b_rows_totals"]["FETCH_SIZE"]["sum_KiB"]) * 1024.0 * 2.0 / acq
-    acq_w = c4["K2b_rows_totals"]["WRITE_SIZE"]["launches"] / 8.0
+    acq_w = c4["K2b_rows_totals"]["WRITE_SIZE"]["launches"] / C4_BATCHES
     write = (c4["K2a_cols_totals"]["WRITE_SIZE"]["sum_KiB"] + c4["K2b_rows_totals"]["WRITE_SIZE"]["sum_KiB"]) * 1024.0 / acq_w
     traffic["fourstep_c4_fetch_bytes_per_launch"] = fetch
     traffic["fourstep_c4_write_bytes_per_launch"] = write
     traffic["fourstep_c4_hbm_bytes_per_launch"] = fetch + write
-    traffic["fourstep_c4_note"] = "per acquisition of 1000 frames = 8 batches of K2a + K2b; the intermediate Y is written and read once"
+    traffic["fourstep_c4_note"] = "per acquisition of 1000 frames = one launch of K2a + one of K2b; the intermediate Y is written and read once"
 except (KeyError, ZeroDivisionError):
     pass
 
