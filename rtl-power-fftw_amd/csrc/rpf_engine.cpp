@@ -486,7 +486,7 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
     if (!tuned && !generic)
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT,
                     "No gfx950 kernel for " + std::to_string(cfg->N) +
-                        " bins in this build (supported: every even N up to 1048576 and the powers of two up to 16777216).");
+                        " bins in this build (supported: every even N up to 8388608 and the powers of two up to 67108864).");
     if (cfg->n_buffers < 1)
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT, "Argument to 'buffers' must be a positive number.");
     if (cfg->buffer_capacity < 2 || (cfg->buffer_capacity % 2) != 0)

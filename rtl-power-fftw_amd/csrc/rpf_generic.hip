@@ -140,12 +140,12 @@ int ilog2i(long v)
 
 }  // namespace
 
-// N even, not covered by the tuned families; pow2 N <= 2^24, other even N <= 2^20 (M <= 2^21).
+// N even, not covered by the tuned families; pow2 N <= 2^26, other even N <= 2^23 (Bluestein length M <= 2^24).
 bool generic_supported(int N)
 {
     if (N < 2 || (N & 1)) return false;
     const bool pow2 = (N & (N - 1)) == 0;
-    return pow2 ? N <= (1 << 24) : N <= (1 << 20);
+    return pow2 ? N <= (1 << 26) : N <= (1 << 23);
 }
 
 int generic_length(int N)       // transform length: N itself, or Bluestein's M

@@ -113,7 +113,7 @@ hipError_t launch_bigblu(int N, bool use_dma, const uint8_t* d_stream, long nfra
                          const cf* d_tw_m2, const cf* d_step_tw, const cf* d_step_tw2, const cf* d_g_t,
                          const cf* d_bhat_t, cf* d_scratch, double* d_partial, int max_grid, hipStream_t stream);
 
-// ---- generic path (rpf_generic.hip): every other even N -- powers of two up to 2^24, others up to 2^20 --
+// ---- generic path (rpf_generic.hip): every other even N -- powers of two up to 2^26, others up to 2^23 --
 bool generic_supported(int N);
 int generic_length(int N);              // N, or Bluestein's M = 2^ceil(log2(2N-1))
 int generic_batch(int N);

@@ -35,16 +35,16 @@ def test_supported_sizes():
     lib = rpf.load()
     for n in (2, 6, 32, 64, 128, 256, 500, 512, 1000, 1024, 2046, 2048, 3000, 4094, 4096, 8192, 16384,
               32768, 65536, 131072, 262144, 4098, 5000, 16386, 100000, 131070,
-              131074, 200000, 524288, 999998, 1048576, 1 << 22, 1 << 24):      # catch-all Stockham path
+              131074, 200000, 524288, 999998, 1048576, 1 << 22, 1 << 24, 3000000, 1 << 23, 1 << 26):      # catch-all Stockham path
         assert lib.rpf_supported_n(n) == 1
-    for n in (0, 1, 513, 1048578, 3000000, 1 << 25):
+    for n in (0, 1, 513, (1 << 23) + 2, 10000000, 1 << 27):
         assert lib.rpf_supported_n(n) == 0
 
 
 def test_invalid_arguments_map_to_reference_exit_codes():
     # exit codes of /root/reference/src/exceptions.h:25-34
     with pytest.raises(rpf.RPFError) as e:
-        rpf.Datastore(rpf.Params(N=3000000))                  # no kernel for this size
+        rpf.Datastore(rpf.Params(N=10000000))                 # no kernel for this size
     assert e.value.retval == rpf.ReturnValue.InvalidArgument
     with pytest.raises(rpf.RPFError) as e:
         rpf.Datastore(rpf.Params(N=511))                      # odd (params.cxx:150-155 bumps it upstream)

@@ -337,6 +337,28 @@ def test_catch_all_sizes_match_oracle(N, windows, torch_dev):
         assert abs(got.sum() / truth.sum() - 1) < 5e-7
 
 
+@pytest.mark.parametrize("N", [3000000, 1 << 25])
+def test_catch_all_reaches_beyond_a_million_bins(N, torch_dev):
+    """The reference's only bound on N is `int` (params.cxx:138,150-155).  The catch-all path takes every even N up to
+    2^23 and every power of two up to 2^26; two frames of 3 000 000 bins (Bluestein on a 2^23-point transform) and of
+    2^25 bins against the float32 oracle and float64 truth.  Two float32 FFTs of this length differ by more than 1e-6 in
+    their weakest bins whoever computes them (the CPU oracle is 1.2e-6 / 1.9e-6 from the truth here): judged against
+    max(bin, median bin) like the other few-frame cases."""
+    R = 2
+    stream = rpf.synth.uniform_iq(900 + N % 7, N * R)
+    with rpf.Datastore(rpf.Params(N=N, repeats=R)) as ds:
+        got, n = run_device(ds, stream, R, torch_dev)
+    assert n == R
+    truth = truth_f64(N, stream, R)
+    o32, _ = oracle_accumulate(N, stream, R, None, 32)
+    e_gpu, e_orc = max_err_over_mean(got, truth), max_err_over_mean(o32, truth)
+    print("N=%d: gpu vs truth %.2e, oracle vs truth %.2e, gpu vs oracle %.2e" % (N, e_gpu, e_orc, max_err_over_mean(got, o32)))
+    # (Bluestein = two float32 transforms of the padded length and two chirp products: up to twice the direct
+    # transform's distance from the truth)
+    assert e_gpu < max(PARITY, 2 * e_orc)
+    assert abs(got.sum() / truth.sum() - 1) < 5e-7
+
+
 def test_known_answers_on_device(torch_dev):
     N, R = 4096, 1000
     with rpf.Datastore(rpf.Params(N=N, repeats=R)) as ds:
