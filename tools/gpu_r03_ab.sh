@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B on ONE box: round 2's library (git HEAD tree under .ab_r02) against the working tree
+# A/B on ONE box: another tree (e.g. `git archive <rev> | tar -x -C .ab_r02` + make, git-ignored) against the working
+# tree, and the scan kernel on one-hop scans (tuning build) beside both: K1 fixed cost + the driver-style bench line.
 set -u
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/r03ab
