@@ -182,10 +182,13 @@ RPF_HD void mix_unpack(const uint32_t* raw, float sgn, const float* wsgn, cf* v)
 //   mix_split_accumulate<J == 0>: v[i] (+)= x_j[i] W_P^{j p} for the thread's PPT0 samples i = g R_0 + n1
 //     raw: the section's samples, one per register (the two buffers of the pipeline are loaded and consumed
 //     without a packing step in between, which would wait for the loads where they are issued);
-//     w: its window values at ntail = t (plain, WINDOW only); wpj = W_P^{j p}
+//     w: its window values (see WM below); wpj = W_P^{j p}
 //   mix_split_mid: v[g R_0 + n1] *= mid[n1]
 // M is even, so (-1)^(n + j M) does not depend on j.
-template <class PL, bool WINDOW, bool FIRST, int I = 0>
+// WM: where the window values of the section come from -- 0: no window; 1: w[ntail + n1 S_0] (global memory,
+// plain values); 2: w[i], the thread's PPT0 values in registers (plain, fetched a section ahead like the raw
+// samples); 3: w[ntail + n1 S_0] in the workgroup's LDS copy of window[n] (-1)^n (sign included).
+template <class PL, int WM, bool FIRST, int I = 0>
 RPF_HD void mix_split_accumulate(const uint32_t* raw, const float* sgn, const float* w, cf wpj, cf* v)
 {
     if constexpr (I < PL::PPT0) {
@@ -193,11 +196,13 @@ RPF_HD void mix_split_accumulate(const uint32_t* raw, const float* sgn, const fl
         const float sg = ((n1 * PL::S(0)) & 1) ? -sgn[g] : sgn[g];
         const cf f = iq_plus_2p23(raw[I]);
         cf x;
-        if constexpr (WINDOW) x = (f - (kTwo23 + 127.0f)) * (w[g * PL::TPF(0) + n1 * PL::S(0)] * sg);   // one rounding
+        if constexpr (WM == 1) x = (f - (kTwo23 + 127.0f)) * (w[g * PL::TPF(0) + n1 * PL::S(0)] * sg);   // one rounding
+        else if constexpr (WM == 2) x = (f - (kTwo23 + 127.0f)) * (w[I] * sg);
+        else if constexpr (WM == 3) x = (f - (kTwo23 + 127.0f)) * w[g * PL::TPF(0) + n1 * PL::S(0)];
         else x = f * sg - (kTwo23 + 127.0f) * sg;                                                          // exact
         if constexpr (FIRST) v[I] = x;
         else v[I] = v[I] + cmul_k(x, wpj);          // (wpj, mid: the same in every lane -- scalar registers)
-        mix_split_accumulate<PL, WINDOW, FIRST, I + 1>(raw, sgn, w, wpj, v);
+        mix_split_accumulate<PL, WM, FIRST, I + 1>(raw, sgn, w, wpj, v);
     }
 }
 template <class PL, int I = 0>

@@ -376,9 +376,10 @@ __global__ __launch_bounds__(PL::WG) void mixed_plan_kernel(const uint8_t* __res
 // mixed_plans_split.inc (20000 ... 80000 bins and 32768; large Bluestein served them at 0.04 Tsample/s).
 // sections J, J + 1, ... of the frame: while section J is unpacked and added to v, section J + 1 is in flight
 // into the other raw buffer (and, after the last one, section 0 of the workgroup's next frame)
-template <class PL, int P, bool WINDOW, int J, class Load>
-__device__ __forceinline__ void split_sections(uint32_t (*raw)[PL::PPT0], const float* sgn, const float* w, const cf* wp, cf* v,
-                                               const Load& load_next_frame_section0, const uint8_t* frame)
+template <class PL, int P, int WM, int J, class Load>
+__device__ __forceinline__ void split_sections(uint32_t (*raw)[PL::PPT0], float (*wv)[WM == 2 ? PL::PPT0 : 1], const float* sgn,
+                                               const float* w, const cf* wp, cf* v, const Load& load_next_frame_section0,
+                                               const uint8_t* frame)
 {
     if constexpr (J < P) {
         constexpr int T0 = PL::TPF(0), R0 = PL::R(0), S0 = PL::S(0);
@@ -387,21 +388,30 @@ __device__ __forceinline__ void split_sections(uint32_t (*raw)[PL::PPT0], const 
 #pragma unroll
             for (int i = 0; i < PL::PPT0; ++i)
                 raw[(J + 1) & 1][i] = *reinterpret_cast<const uint16_t*>(base + 2 * ((i / R0) * T0 + (i % R0) * S0));
+            if constexpr (WM == 2) {
+#pragma unroll
+                for (int i = 0; i < PL::PPT0; ++i) wv[(J + 1) & 1][i] = w[(J + 1) * PL::N + (i / R0) * T0 + (i % R0) * S0];
+            }
         } else {
-            load_next_frame_section0(raw[(J + 1) & 1]);
+            load_next_frame_section0(raw[(J + 1) & 1], wv[(J + 1) & 1]);
         }
-        mix_split_accumulate<PL, WINDOW, J == 0>(raw[J & 1], sgn, WINDOW ? w + J * PL::N : w, wp[J], v);
-        split_sections<PL, P, WINDOW, J + 1>(raw, sgn, w, wp, v, load_next_frame_section0, frame);
+        mix_split_accumulate<PL, WM, J == 0>(raw[J & 1], sgn, WM == 2 ? wv[J & 1] : WM != 0 ? w + J * PL::N : w, wp[J], v);
+        split_sections<PL, P, WM, J + 1>(raw, wv, sgn, w, wp, v, load_next_frame_section0, frame);
     }
 }
 
-template <class PL, int P, bool WINDOW>
+// WM: how a windowed run gets its window values (mix_split_accumulate): 1 = loaded where they are used (every
+// section waits for its loads: one workgroup per CU has nothing else to run meanwhile); 2 = fetched one section
+// ahead, with the raw samples (PPT0 more registers); 3 = window[n] (-1)^n for the whole frame in LDS, filled once
+// per workgroup (4 N bytes beside the M-point slab).
+template <class PL, int P, int WM>
 __global__ __launch_bounds__(PL::WG) void mixed_split_kernel(const uint8_t* __restrict__ stream, long nframes,
                                                             const cf* __restrict__ twN, const float* __restrict__ window,
                                                             double* __restrict__ partial)
 {
     static_assert(PL::TW != 1 && PL::FPW == 1 && PL::N % 2 == 0, "pass-0 twiddles in registers, one frame slot, even M");
     constexpr int M = PL::N, N = P * M, R0 = PL::R(0), G0 = PL::G(0), T0 = PL::TPF(0), S0 = PL::S(0);
+    static_assert(WM != 3 || PL::LDS_BYTES + 4 * N <= 160 * 1024, "no room for the window in LDS");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
     // The P workgroups of a frame read the same bytes: put them on one XCD (workgroups go to the 8 XCDs round-robin by
@@ -413,11 +423,15 @@ __global__ __launch_bounds__(PL::WG) void mixed_split_kernel(const uint8_t* __re
     const int group = xcd_local ? (blockIdx.x % 8) + 8 * (q / P) : blockIdx.x / P;
     cf* const slab = reinterpret_cast<cf*>(smem);
     cf* const table = reinterpret_cast<cf*>(smem) + PL::LDS_CPX;
+    float* const wlds = reinterpret_cast<float*>(table + PL::TABLE_ENTRIES);      // WM == 3
     const bool in0 = T0 == PL::TPFMAX || t < T0;
 
     cf tw[PL::NTW_REG > 0 ? PL::NTW_REG : 1];                    // (pass 0's block is unused here)
     plan_load_twiddles<PL, 0, P>(t, twN, tw);
     if constexpr (PL::TW == 2) plan_fill_shared_table<PL, 1, P>(t, twN, table);
+    if constexpr (WM == 3) {
+        for (int n = t; n < N; n += PL::WG) wlds[n] = window[n] * ((n & 1) ? -1.0f : 1.0f);        // datastore.cxx:73,76-77
+    }
     // pass 0: output k of the butterfly with ntail carries W_N^{ntail p} W_M^{ntail k} = W_N^{ntail (p + P k)}
     cf tw0[G0 * R0];
     float sgn[G0];
@@ -438,16 +452,24 @@ __global__ __launch_bounds__(PL::WG) void mixed_split_kernel(const uint8_t* __re
     for (int a = 0; a < PL::PPTL; ++a) acc[a] = 0.0;
 
     uint32_t raw[2][PL::PPT0];          // one sample per register (mix_split_accumulate)
-    auto load_section0 = [&](long frame, uint32_t* dst) {
+    float wv[2][WM == 2 ? PL::PPT0 : 1];
+    auto load_section0 = [&](long frame, uint32_t* dst, float* wdst) {
         const uint8_t* const base = stream + (frame < nframes ? frame : nframes - 1) * (2L * N) + 2 * t;
 #pragma unroll
         for (int i = 0; i < PL::PPT0; ++i) dst[i] = *reinterpret_cast<const uint16_t*>(base + 2 * ((i / R0) * T0 + (i % R0) * S0));
+        if constexpr (WM == 2) {
+            // (opaque per frame: otherwise the compiler keeps section 0's values in registers across the loop)
+            const float* w0 = window + t;
+            asm volatile("" : "+v"(w0));
+#pragma unroll
+            for (int i = 0; i < PL::PPT0; ++i) wdst[i] = w0[(i / R0) * T0 + (i % R0) * S0];
+        }
     };
     const long stride = gridDim.x / P;
     long fb = group;
     // section j of a frame lives in raw[j & 1]; the last section's turn puts the next frame's section 0 into
     // raw[P & 1] -- for odd P that is raw[1], moved to raw[0] at the top of the next frame (long landed by then)
-    if (in0) load_section0(fb, raw[P & 1]);
+    if (in0) load_section0(fb, raw[P & 1], wv[P & 1]);
     __syncthreads();
 #pragma unroll 1
     for (; fb < nframes; fb += stride) {
@@ -456,15 +478,19 @@ __global__ __launch_bounds__(PL::WG) void mixed_split_kernel(const uint8_t* __re
             if constexpr (P % 2 == 1) {
 #pragma unroll
                 for (int r = 0; r < PL::PPT0; ++r) raw[0][r] = raw[1][r];
+                if constexpr (WM == 2) {
+#pragma unroll
+                    for (int r = 0; r < PL::PPT0; ++r) wv[0][r] = wv[1][r];
+                }
             }
             const uint8_t* const frame = stream + fb * (2L * N) + 2 * t;
             // (opaque per frame: otherwise the compiler hoists the loop-invariant window loads out of the frame
             // loop and spills them)
-            const float* w = window + t;
-            if constexpr (WINDOW) asm volatile("" : "+v"(w));
+            const float* w = WM == 3 ? wlds + t : window + t;
+            if constexpr (WM == 1 || WM == 2) asm volatile("" : "+v"(w));
             const long next = fb + stride;
-            auto next0 = [&](uint32_t* dst) { load_section0(next, dst); };
-            split_sections<PL, P, WINDOW, 0>(raw, sgn, w, wp, v, next0, frame);
+            auto next0 = [&](uint32_t* dst, float* wdst) { load_section0(next, dst, wdst); };
+            split_sections<PL, P, WM, 0>(raw, wv, sgn, w, wp, v, next0, frame);
             mix_split_mid<PL>(v, mid);
         }
         exchange_sync<true>();                   // the previous frame's last pass has left the slab
@@ -494,11 +520,17 @@ __global__ __launch_bounds__(PL::WG) void mixed_split_kernel(const uint8_t* __re
 }
 
 using PlanFn = void (*)(const uint8_t*, long, const cf*, const float*, double*);
+// One way of running a size: the kernel, its workgroup, frames per workgroup, LDS, and the split factor (1: the
+// planned kernel; P: the split form, N = P x the plan's length).  A size has one for plain runs and one for windowed
+// runs -- not necessarily the same plan: the window wants registers or LDS the fastest plain plan may not have left.
+struct PlanForm {
+    PlanFn fn;
+    int wg, fpw, lds, split;
+};
 struct PlanEntry {
     int N, variant;
-    PlanFn plain, windowed;
-    int wg, fpw, lds, lds_windowed;
-    int split;          // 1, or the factor P of the split form (N = P x the plan's length)
+    PlanForm plain, windowed;
+    const PlanForm& form(bool w) const { return w ? windowed : plain; }
 };
 template <class PL>
 constexpr int plan_lds_bytes(bool windowed)
@@ -506,17 +538,32 @@ constexpr int plan_lds_bytes(bool windowed)
     return PL::LDS_BYTES +
            (windowed && PL::WLDS ? PL::N * (int)sizeof(float) : 0);
 }
+template <class PL, bool WINDOW>
+constexpr PlanForm plan_form()
+{
+    return {mixed_plan_kernel<PL, WINDOW>, PL::WG, PL::FPW, plan_lds_bytes<PL>(WINDOW), 1};
+}
+// the split form's window mode when the table does not name one: the LDS copy where it fits, else loads in place
+template <int P, class PL>
+constexpr int split_window_mode()
+{
+    return PL::LDS_BYTES + 4 * P * PL::N <= 160 * 1024 ? 3 : 1;
+}
+template <int P, class PL, int WM>
+constexpr PlanForm split_form()
+{
+    return {mixed_split_kernel<PL, P, WM>, PL::WG, 1, PL::LDS_BYTES + (WM == 3 ? 4 * P * PL::N : 0), P};
+}
 template <class PL>
 constexpr PlanEntry plan_entry(int variant)
 {
-    return {PL::N, variant, mixed_plan_kernel<PL, false>, mixed_plan_kernel<PL, true>, PL::WG, PL::FPW,
-            plan_lds_bytes<PL>(false), plan_lds_bytes<PL>(true), 1};
+    return {PL::N, variant, plan_form<PL, false>(), plan_form<PL, true>()};
 }
-template <int P, class PL>
+// (WM: window mode of the windowed twin, mixed_split_kernel; 0 = split_window_mode's choice)
+template <int P, class PL, int WM = 0>
 constexpr PlanEntry split_entry(int variant)
 {
-    return {P * PL::N, variant, mixed_split_kernel<PL, P, false>, mixed_split_kernel<PL, P, true>, PL::WG, 1,
-            PL::LDS_BYTES, PL::LDS_BYTES, P};
+    return {P * PL::N, variant, split_form<P, PL, 0>(), split_form<P, PL, WM ? WM : split_window_mode<P, PL>()>()};
 }
 template <int R, int G = 1>
 using P = MPass<R, G>;
@@ -527,7 +574,7 @@ using P = MPass<R, G>;
 template <class PL>
 constexpr PlanEntry plan_candidate(int variant)
 {
-    return {PL::N, variant, mixed_plan_kernel<PL, false>, nullptr, PL::WG, PL::FPW, plan_lds_bytes<PL>(false), 0, 1};
+    return {PL::N, variant, plan_form<PL, false>(), PlanForm{nullptr, 0, 0, 0, 1}};
 }
 #endif
 const PlanEntry kPlans[] = {
@@ -542,6 +589,26 @@ const PlanEntry* find_plan(int N, int variant)
     for (const PlanEntry& e : kPlans)
         if (e.N == N && e.variant == variant) return &e;
     return nullptr;
+}
+// Runs of the shipped sizes (variant 0) that do better on another form than the entry above gives them --
+// mostly windowed runs, whose window values want registers or LDS the fastest plain plan has not left:
+// mixed_plans_override.inc, picked from GPU timings (tools/gen_mixed_plans.py winsearch / splitsearch).
+struct FormOverride {
+    int N;
+    bool windowed;
+    PlanForm form;
+};
+const FormOverride kFormOverrides[] = {
+#include "mixed_plans_override.inc"
+};
+// how size N runs (nullptr: not a planned size; fn == nullptr: a tuning-build candidate without a windowed twin)
+const PlanForm* find_form(int N, int variant, bool windowed)
+{
+    if (variant == 0)
+        for (const FormOverride& o : kFormOverrides)
+            if (o.N == N && o.windowed == windowed) return &o.form;
+    const PlanEntry* pe = find_plan(N, variant);
+    return pe ? &pe->form(windowed) : nullptr;
 }
 
 bool factorise(int N, MixedPlan* plan)
@@ -599,12 +666,11 @@ bool mixed_supported(int N, int variant)
 hipError_t plan_mixed(int N, int variant, bool windowed, int device, LaunchInfo* li)
 {
     if (!mixed_supported(N, variant)) return hipErrorInvalidValue;
-    const PlanEntry* pe = find_plan(N, variant);
-    if (pe && windowed && !pe->windowed) return hipErrorInvalidValue;      // (a tuning-build candidate)
-    const int lds = pe ? (windowed ? pe->lds_windowed : pe->lds) : lds_bytes(N);
-    const int wg = pe ? pe->wg : kMixedWG;
-    const void* fn = pe ? reinterpret_cast<const void*>(windowed ? pe->windowed : pe->plain)
-                        : reinterpret_cast<const void*>(mixed_kernel);
+    const PlanForm* pf = find_form(N, variant, windowed);
+    if (pf && !pf->fn) return hipErrorInvalidValue;      // (a tuning-build candidate without its windowed twin)
+    const int lds = pf ? pf->lds : lds_bytes(N);
+    const int wg = pf ? pf->wg : kMixedWG;
+    const void* fn = pf ? reinterpret_cast<const void*>(pf->fn) : reinterpret_cast<const void*>(mixed_kernel);
     hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (err != hipSuccess) return err;
     int per_cu = 0;
@@ -613,16 +679,16 @@ hipError_t plan_mixed(int N, int variant, bool windowed, int device, LaunchInfo*
     hipDeviceProp_t prop;
     if ((err = hipGetDeviceProperties(&prop, device)) != hipSuccess) return err;
     li->grid = std::max(per_cu, 1) * prop.multiProcessorCount;
-    if (pe && pe->split > 1) {
+    if (pf && pf->split > 1) {
         // split form: whole rounds of the 8 XCDs (its XCD-local mapping) where the device has that many
         // resident workgroups, else any multiple of the split factor; a device too small for even one
         // group gets no plan, and rpf_engine_create takes the next kernel family
-        const int unit = li->grid >= 8 * pe->split ? 8 * pe->split : pe->split;
+        const int unit = li->grid >= 8 * pf->split ? 8 * pf->split : pf->split;
         li->grid -= li->grid % unit;
-        if (li->grid < pe->split) return hipErrorInvalidValue;
+        if (li->grid < pf->split) return hipErrorInvalidValue;
     }
     li->block = wg;
-    li->fpw = pe ? pe->fpw : kMixedWG / threads_per_frame(N);
+    li->fpw = pf ? pf->fpw : kMixedWG / threads_per_frame(N);
     li->lds_bytes = lds;
     return hipSuccess;
 }
@@ -632,17 +698,17 @@ hipError_t launch_mixed(int N, int variant, const uint8_t* d_stream, long nframe
                         double* d_partial, int max_grid, hipStream_t stream, LaunchInfo* li)
 {
     if (!mixed_supported(N, variant) || max_grid < 1 || nframes < 1) return hipErrorInvalidValue;
-    int wg = kMixedWG, fpw = 0, lds = 0, grid = 0;
-    if (const PlanEntry* pe = find_plan(N, variant)) {
-        wg = pe->wg, fpw = pe->fpw, lds = d_window ? pe->lds_windowed : pe->lds;
-        if (d_window && !pe->windowed) return hipErrorInvalidValue;      // (a tuning-build candidate)
+    int wg = kMixedWG, fpw = 0, lds = 0, grid = 0, split = 1;
+    if (const PlanForm* pform = find_form(N, variant, d_window != nullptr)) {
+        const PlanForm& pf = *pform;
+        if (!pf.fn) return hipErrorInvalidValue;      // (a tuning-build candidate without its windowed twin)
+        wg = pf.wg, fpw = pf.fpw, lds = pf.lds, split = pf.split;
         // no more workgroups than frames to share out (x the split factor: one workgroup per residue)
-        long groups = std::min<long>(max_grid / pe->split, (nframes + fpw - 1) / fpw);
-        if (pe->split > 1 && groups > 8) groups -= groups % 8;        // whole rounds of the 8 XCDs
+        long groups = std::min<long>(max_grid / split, (nframes + fpw - 1) / fpw);
+        if (split > 1 && groups > 8) groups -= groups % 8;        // whole rounds of the 8 XCDs
         if (groups < 1) return hipErrorInvalidValue;
-        grid = static_cast<int>(groups) * pe->split;
-        hipLaunchKernelGGL(d_window ? pe->windowed : pe->plain, dim3(grid), dim3(wg), lds, stream, d_stream, nframes, d_twN,
-                           d_window, d_partial);
+        grid = static_cast<int>(groups) * split;
+        hipLaunchKernelGGL(pf.fn, dim3(grid), dim3(wg), lds, stream, d_stream, nframes, d_twN, d_window, d_partial);
     } else {
         MixedPlan plan;
         if (!factorise(N, &plan)) return hipErrorInvalidValue;
@@ -653,12 +719,11 @@ hipError_t launch_mixed(int N, int variant, const uint8_t* d_stream, long nframe
                            d_window, d_partial);
     }
     if (li) {
-        const PlanEntry* pe = find_plan(N, variant);
         li->grid = grid;
         li->block = wg;
         li->fpw = fpw;
         li->lds_bytes = lds;
-        li->slots = pe ? grid / pe->split : grid;
+        li->slots = grid / split;
     }
     return hipGetLastError();
 }

@@ -152,7 +152,7 @@ def test_mixed_radix_sizes_match_oracle_and_bluestein(N, torch_dev):
         assert max_rel(got, other) < PARITY
 
 
-@pytest.mark.parametrize("N", [20000, 24000, 25000, 30000, 32768, 36000, 40000, 45000, 50000, 64000, 75000, 80000])
+@pytest.mark.parametrize("N", [16384, 20000, 24000, 25000, 30000, 32000, 32768, 36000, 40000, 45000, 48000, 50000, 64000, 75000, 80000])
 def test_split_mixed_radix_sizes_match_oracle(N, torch_dev):
     """N = P x M (P = 2 ... 5, M <= 16384 one of the planned lengths): the split form of the mixed-radix kernel
     (one workgroup per residue of the spectrum, rpf_mixed.hip) against the float32 oracle, float64 truth and the
@@ -178,7 +178,7 @@ def test_split_mixed_radix_sizes_match_oracle(N, torch_dev):
         assert max_rel(few, truth_f64(N, stream, 3, w)) < 2 * PARITY      # three frames: little averaging
 
 
-THIN_MARGIN_SIZES = [20000, 24000, 25000, 30000, 32000, 32768, 36000, 40000, 45000, 48000, 50000, 60000, 64000, 75000,
+THIN_MARGIN_SIZES = [16384, 20000, 24000, 25000, 30000, 32000, 32768, 36000, 40000, 45000, 48000, 50000, 60000, 64000, 75000,
                      80000, 131072, 262144, 524288]
 
 

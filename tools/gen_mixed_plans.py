@@ -14,6 +14,7 @@ A plan is N = R_0 ... R_{F-1} with G_i butterflies per thread in pass i (R_i G_i
 TPF_i = N / (R_i G_i) threads of a frame take part), FPW frame slots per workgroup and TW = 0
 (twiddles in registers) or 1 (per-thread rows of an LDS table)."""
 import itertools
+import os
 import sys
 
 RADICES = [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25]
@@ -199,9 +200,41 @@ def split_candidates(n):
     return out
 
 
-def split_entry(p, m, rad, gs, variant):
+def split_entry(p, m, rad, gs, variant, wm=0):
     passes = ", ".join("P<%d%s>" % (r, (", %d" % g) if g != 1 else "") for r, g in zip(rad, gs))
-    return "    split_entry<%d, MixPlan<%d, 1, 2, %s>>(%d)," % (p, m, passes, variant)
+    return "    split_entry<%d, MixPlan<%d, 1, 2, %s>%s>(%d)," % (p, m, passes, (", %d" % wm) if wm else "", variant)
+
+
+def measured_split_rates():
+    """(N, P, M, radices, groups) -> Gsample/s of the plain split form, from the committed search results."""
+    import ast, re
+    rates, n = {}, None
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_split_plan_search.txt")
+    if not os.path.exists(path):
+        return rates
+    for line in open(path):
+        m = re.match(r"N=(\d+)", line)
+        if m:
+            n = int(m.group(1))
+            continue
+        m = re.match(r"\s+([\d.]+)\s+\(\S+\)\s+P (\d) M (\d+) (\([\d, ]+\)) (\([\d, ]+\))", line)
+        if m and n:
+            rates[(n, int(m.group(2)), int(m.group(3)), ast.literal_eval(m.group(4)), ast.literal_eval(m.group(5)))] = float(m.group(1))
+    return rates
+
+
+def window_candidates(n, keep=6):
+    """Windowed twins of the split form for size n: (P, M, radices, groups, window mode) -- mode 2 (window values
+    fetched a section ahead) for the `keep` fastest plain candidates, mode 3 (the whole window in LDS) for the `keep`
+    fastest candidates that have the room.  Sizes the plain search did not cover (16384) keep every candidate."""
+    rates = measured_split_rates()
+    cands = split_candidates(n)
+    known = [c for c in cands if (n,) + c in rates]
+    if known:
+        cands = sorted(known, key=lambda c: -rates[(n,) + c])
+    fits = [c for c in cands if lds_bytes(c[1], c[2], c[3], 1, 2) + 4 * n <= LDS_LIMIT]
+    lim = keep if known else len(cands)
+    return [c + (2,) for c in cands[:lim]] + [c + (3,) for c in fits[:lim]]
 
 
 def variant_base(n):
@@ -230,6 +263,20 @@ def main():
         return
     if mode == "splitcases":
         print(" ".join("%d:%d" % (n, v + variant_base(n)) for n in sizes for v in range(11, 11 + len(split_candidates(n)))))
+        return
+    if mode == "winsearch":        # windowed twins of split candidates, variants 11, 12, ... (tuning build)
+        print("// generated by tools/gen_mixed_plans.py winsearch -- tuning build only")
+        for n in sizes:
+            for v, (p, m, rad, gs, wm) in enumerate(window_candidates(n), start=11 + variant_base(n)):
+                print(split_entry(p, m, rad, gs, v, wm))
+        return
+    if mode == "wincases":
+        print(" ".join("%d:%d" % (n, v + variant_base(n)) for n in sizes for v in range(11, 11 + len(window_candidates(n)))))
+        return
+    if mode == "winlist":
+        for n in sizes:
+            for v, (p, m, rad, gs, wm) in enumerate(window_candidates(n), start=11 + variant_base(n)):
+                print(n, v, "P", p, "M", m, rad, gs, "WM", wm)
         return
     if mode == "splitlist":
         for n in sizes:

@@ -1,7 +1,8 @@
 """Kernel-only timing (HIP events on the launch stream) + parity of every kernel
 variant.  Usage: python tools/gpu_sweep.py [N:variant ...]
 Variants other than 0 exist only in the tuning build: RPF_ENGINE_LIB=rtl-power-fftw_amd/librpf_engine_tuning.so
-(make -C rtl-power-fftw_amd/csrc tuning).  SWEEP_NOWIN=1 skips the windowed cases."""
+(make -C rtl-power-fftw_amd/csrc tuning).  SWEEP_NOWIN=1 skips the windowed cases, SWEEP_ONLYWIN=1 the plain ones;
+SWEEP_K: timed launches per case (400)."""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,7 +33,7 @@ s = torch.cuda.current_stream().cuda_stream
 for case in cases:
     N, vid = (int(v) for v in case.split(":"))
     R = TOTAL // N
-    for win in ((False,) if os.environ.get("SWEEP_NOWIN") else (False, True)):
+    for win in ((False,) if os.environ.get("SWEEP_NOWIN") else (True,) if os.environ.get("SWEEP_ONLYWIN") else (False, True)):
         w = rpf.synth.hann_window(N) if win else None
         try:
             ds = rpf.Datastore(rpf.Params(N=N, window=win, repeats=R), w, flags=(vid << 8))
@@ -53,10 +54,10 @@ for case in cases:
             ref_full[(N, win)] = full
         same = "ref" if vid == 0 else ("n/a" if (N, win) not in ref_full else
                                        "max_rel_vs_v0 %.1e" % float(np.max(np.abs(full - ref_full[(N, win)]) / ref_full[(N, win)])))
-        for i in range(200):
+        K = int(os.environ.get("SWEEP_K", "400"))
+        for i in range(K // 2):
             ds.device_fused(bufs[i % NB].data_ptr(), 2 * N * R, R, s)
         torch.cuda.synchronize()
-        K = 400
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(K):
