@@ -188,20 +188,29 @@ RPF_HD void mix_unpack(const uint32_t* raw, float sgn, const float* wsgn, cf* v)
 // WM: where the window values of the section come from -- 0: no window; 1: w[ntail + n1 S_0] (global memory,
 // plain values); 2: w[i], the thread's PPT0 values in registers (plain, fetched a section ahead like the raw
 // samples); 3: w[ntail + n1 S_0] in the workgroup's LDS copy of window[n] (-1)^n (sign included).
+// one sample of the section: raw_i = its 16-bit IQ pair, wi = its window value (WM 1, 2: plain; 3: sign included)
+template <class PL, int WM, bool FIRST, int I>
+RPF_HD void mix_split_element(uint32_t raw_i, const float* sgn, float wi, cf wpj, cf* v)
+{
+    constexpr int g = I / PL::R(0), n1 = I % PL::R(0);
+    const float sg = ((n1 * PL::S(0)) & 1) ? -sgn[g] : sgn[g];
+    const cf f = iq_plus_2p23(raw_i);
+    cf x;
+    if constexpr (WM == 1 || WM == 2) x = (f - (kTwo23 + 127.0f)) * (wi * sg);      // one rounding
+    else if constexpr (WM == 3) x = (f - (kTwo23 + 127.0f)) * wi;
+    else x = f * sg - (kTwo23 + 127.0f) * sg;                                       // exact
+    if constexpr (FIRST) v[I] = x;
+    else v[I] = v[I] + cmul_k(x, wpj);          // (wpj, mid: the same in every lane -- scalar registers)
+}
 template <class PL, int WM, bool FIRST, int I = 0>
 RPF_HD void mix_split_accumulate(const uint32_t* raw, const float* sgn, const float* w, cf wpj, cf* v)
 {
     if constexpr (I < PL::PPT0) {
         constexpr int g = I / PL::R(0), n1 = I % PL::R(0);
-        const float sg = ((n1 * PL::S(0)) & 1) ? -sgn[g] : sgn[g];
-        const cf f = iq_plus_2p23(raw[I]);
-        cf x;
-        if constexpr (WM == 1) x = (f - (kTwo23 + 127.0f)) * (w[g * PL::TPF(0) + n1 * PL::S(0)] * sg);   // one rounding
-        else if constexpr (WM == 2) x = (f - (kTwo23 + 127.0f)) * (w[I] * sg);
-        else if constexpr (WM == 3) x = (f - (kTwo23 + 127.0f)) * w[g * PL::TPF(0) + n1 * PL::S(0)];
-        else x = f * sg - (kTwo23 + 127.0f) * sg;                                                          // exact
-        if constexpr (FIRST) v[I] = x;
-        else v[I] = v[I] + cmul_k(x, wpj);          // (wpj, mid: the same in every lane -- scalar registers)
+        float wi = 0.0f;
+        if constexpr (WM == 2) wi = w[I];
+        else if constexpr (WM != 0) wi = w[g * PL::TPF(0) + n1 * PL::S(0)];
+        mix_split_element<PL, WM, FIRST, I>(raw[I], sgn, wi, wpj, v);
         mix_split_accumulate<PL, WM, FIRST, I + 1>(raw, sgn, w, wpj, v);
     }
 }

@@ -400,11 +400,44 @@ __device__ __forceinline__ void split_sections(uint32_t (*raw)[PL::PPT0], float 
     }
 }
 
+// ROLL: the same pipeline on ONE buffer -- sample i of the section is consumed and its register (and its window
+// value's, WM == 2) refilled at once with sample i of the NEXT section (after the last one: section 0 of the
+// workgroup's next frame), so each load has a whole section's arithmetic to land and the pipeline costs PPT0
+// registers instead of 2 PPT0 (+ PPT0 instead of 2 PPT0 for the window values).
+//   nraw / nw: the next section's samples / window values at this thread's ntail (nw: global memory)
+template <class PL, int WM, bool FIRST, int I = 0>
+__device__ __forceinline__ void split_section_rolling(uint32_t* raw, float* wv, const float* sgn, const float* wl, cf wpj, cf* v,
+                                                      const uint8_t* nraw, const float* nw)
+{
+    if constexpr (I < PL::PPT0) {
+        constexpr int T0 = PL::TPF(0), R0 = PL::R(0), S0 = PL::S(0);
+        constexpr int off = (I / R0) * T0 + (I % R0) * S0;
+        float wi = 0.0f;
+        if constexpr (WM == 2) wi = wv[I];
+        else if constexpr (WM == 3) wi = wl[off];
+        mix_split_element<PL, WM, FIRST, I>(raw[I], sgn, wi, wpj, v);
+        raw[I] = *reinterpret_cast<const uint16_t*>(nraw + 2 * off);
+        if constexpr (WM == 2) wv[I] = nw[off];
+        split_section_rolling<PL, WM, FIRST, I + 1>(raw, wv, sgn, wl, wpj, v, nraw, nw);
+    }
+}
+template <class PL, int P, int WM, int J = 0>
+__device__ __forceinline__ void split_sections_rolling(uint32_t* raw, float* wv, const float* sgn, const float* wl, const float* w,
+                                                       const cf* wp, cf* v, const uint8_t* frame, const uint8_t* next_frame)
+{
+    if constexpr (J < P) {
+        const uint8_t* const nraw = J + 1 < P ? frame + 2L * (J + 1) * PL::N : next_frame;
+        const float* const nw = J + 1 < P ? w + (J + 1) * PL::N : w;
+        split_section_rolling<PL, WM, J == 0>(raw, wv, sgn, WM == 3 ? wl + J * PL::N : wl, wp[J], v, nraw, nw);
+        split_sections_rolling<PL, P, WM, J + 1>(raw, wv, sgn, wl, w, wp, v, frame, next_frame);
+    }
+}
+
 // WM: how a windowed run gets its window values (mix_split_accumulate): 1 = loaded where they are used (every
 // section waits for its loads: one workgroup per CU has nothing else to run meanwhile); 2 = fetched one section
 // ahead, with the raw samples (PPT0 more registers); 3 = window[n] (-1)^n for the whole frame in LDS, filled once
 // per workgroup (4 N bytes beside the M-point slab).
-template <class PL, int P, int WM>
+template <class PL, int P, int WM, bool ROLL = false>
 __global__ __launch_bounds__(PL::WG) void mixed_split_kernel(const uint8_t* __restrict__ stream, long nframes,
                                                             const cf* __restrict__ twN, const float* __restrict__ window,
                                                             double* __restrict__ partial)
@@ -412,6 +445,7 @@ __global__ __launch_bounds__(PL::WG) void mixed_split_kernel(const uint8_t* __re
     static_assert(PL::TW != 1 && PL::FPW == 1 && PL::N % 2 == 0, "pass-0 twiddles in registers, one frame slot, even M");
     constexpr int M = PL::N, N = P * M, R0 = PL::R(0), G0 = PL::G(0), T0 = PL::TPF(0), S0 = PL::S(0);
     static_assert(WM != 3 || PL::LDS_BYTES + 4 * N <= 160 * 1024, "no room for the window in LDS");
+    static_assert(!ROLL || WM != 1, "the rolling pipeline fetches its window values ahead (2) or keeps them in LDS (3)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
     // The P workgroups of a frame read the same bytes: put them on one XCD (workgroups go to the 8 XCDs round-robin by
@@ -451,8 +485,8 @@ __global__ __launch_bounds__(PL::WG) void mixed_split_kernel(const uint8_t* __re
 #pragma unroll
     for (int a = 0; a < PL::PPTL; ++a) acc[a] = 0.0;
 
-    uint32_t raw[2][PL::PPT0];          // one sample per register (mix_split_accumulate)
-    float wv[2][WM == 2 ? PL::PPT0 : 1];
+    uint32_t raw[ROLL ? 1 : 2][PL::PPT0];          // one sample per register (mix_split_accumulate)
+    float wv[ROLL ? 1 : 2][WM == 2 ? PL::PPT0 : 1];
     auto load_section0 = [&](long frame, uint32_t* dst, float* wdst) {
         const uint8_t* const base = stream + (frame < nframes ? frame : nframes - 1) * (2L * N) + 2 * t;
 #pragma unroll
@@ -467,30 +501,36 @@ __global__ __launch_bounds__(PL::WG) void mixed_split_kernel(const uint8_t* __re
     };
     const long stride = gridDim.x / P;
     long fb = group;
-    // section j of a frame lives in raw[j & 1]; the last section's turn puts the next frame's section 0 into
-    // raw[P & 1] -- for odd P that is raw[1], moved to raw[0] at the top of the next frame (long landed by then)
-    if (in0) load_section0(fb, raw[P & 1], wv[P & 1]);
+    // two buffers: section j of a frame lives in raw[j & 1]; the last section's turn puts the next frame's section 0
+    // into raw[P & 1] -- for odd P that is raw[1], moved to raw[0] at the top of the next frame (long landed by then)
+    constexpr int B0 = ROLL ? 0 : (P & 1);
+    if (in0) load_section0(fb, raw[B0], wv[B0]);
     __syncthreads();
 #pragma unroll 1
     for (; fb < nframes; fb += stride) {
         cf v[PL::PPT0];
         if (in0) {
-            if constexpr (P % 2 == 1) {
-#pragma unroll
-                for (int r = 0; r < PL::PPT0; ++r) raw[0][r] = raw[1][r];
-                if constexpr (WM == 2) {
-#pragma unroll
-                    for (int r = 0; r < PL::PPT0; ++r) wv[0][r] = wv[1][r];
-                }
-            }
             const uint8_t* const frame = stream + fb * (2L * N) + 2 * t;
             // (opaque per frame: otherwise the compiler hoists the loop-invariant window loads out of the frame
             // loop and spills them)
             const float* w = WM == 3 ? wlds + t : window + t;
             if constexpr (WM == 1 || WM == 2) asm volatile("" : "+v"(w));
             const long next = fb + stride;
-            auto next0 = [&](uint32_t* dst, float* wdst) { load_section0(next, dst, wdst); };
-            split_sections<PL, P, WM, 0>(raw, wv, sgn, w, wp, v, next0, frame);
+            if constexpr (ROLL) {
+                const uint8_t* const next_frame = stream + (next < nframes ? next : nframes - 1) * (2L * N) + 2 * t;
+                split_sections_rolling<PL, P, WM>(raw[0], wv[0], sgn, w, w, wp, v, frame, next_frame);
+            } else {
+                if constexpr (P % 2 == 1) {
+#pragma unroll
+                    for (int r = 0; r < PL::PPT0; ++r) raw[0][r] = raw[B0][r];
+                    if constexpr (WM == 2) {
+#pragma unroll
+                        for (int r = 0; r < PL::PPT0; ++r) wv[0][r] = wv[B0][r];
+                    }
+                }
+                auto next0 = [&](uint32_t* dst, float* wdst) { load_section0(next, dst, wdst); };
+                split_sections<PL, P, WM, 0>(raw, wv, sgn, w, wp, v, next0, frame);
+            }
             mix_split_mid<PL>(v, mid);
         }
         exchange_sync<true>();                   // the previous frame's last pass has left the slab
@@ -549,21 +589,23 @@ constexpr int split_window_mode()
 {
     return PL::LDS_BYTES + 4 * P * PL::N <= 160 * 1024 ? 3 : 1;
 }
-template <int P, class PL, int WM>
+template <int P, class PL, int WM, bool ROLL = false>
 constexpr PlanForm split_form()
 {
-    return {mixed_split_kernel<PL, P, WM>, PL::WG, 1, PL::LDS_BYTES + (WM == 3 ? 4 * P * PL::N : 0), P};
+    return {mixed_split_kernel<PL, P, WM, ROLL>, PL::WG, 1, PL::LDS_BYTES + (WM == 3 ? 4 * P * PL::N : 0), P};
 }
 template <class PL>
 constexpr PlanEntry plan_entry(int variant)
 {
     return {PL::N, variant, plan_form<PL, false>(), plan_form<PL, true>()};
 }
-// (WM: window mode of the windowed twin, mixed_split_kernel; 0 = split_window_mode's choice)
-template <int P, class PL, int WM = 0>
+// (WM: window mode of the windowed twin, mixed_split_kernel; 0 = split_window_mode's choice.  ROLL: the one-buffer
+// section pipeline, for the plans that have no registers for two)
+template <int P, class PL, int WM = 0, bool ROLL = false>
 constexpr PlanEntry split_entry(int variant)
 {
-    return {P * PL::N, variant, split_form<P, PL, 0>(), split_form<P, PL, WM ? WM : split_window_mode<P, PL>()>()};
+    constexpr int wm = WM ? WM : split_window_mode<P, PL>();
+    return {P * PL::N, variant, split_form<P, PL, 0, ROLL>(), split_form<P, PL, (ROLL && wm == 1) ? 2 : wm, ROLL>()};
 }
 template <int R, int G = 1>
 using P = MPass<R, G>;

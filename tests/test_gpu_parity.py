@@ -126,7 +126,7 @@ def test_non_power_of_two_sizes_match_oracle(N, windowed, torch_dev):
 
 @pytest.mark.parametrize("N", [6, 10, 12, 50, 90, 96, 100, 108, 140, 150, 250, 384, 500, 600, 700, 750, 1000, 1100, 1200, 1300,
                                1458, 1500, 1536, 1700, 1900, 2000, 2300, 2430, 3000, 3600, 3750, 4000, 4050, 4374, 4500, 5000,
-                               5120, 6000, 6250, 6400, 7000, 7500, 7800, 8000, 9000, 9216, 9500, 9720, 9900, 10000, 11000, 12000, 13000, 15000, 15360, 16000, 16384])
+                               5120, 6000, 6250, 6400, 7000, 7500, 7800, 8000, 9000, 9216, 9500, 9720, 9900, 10000, 11000, 12000, 12500, 12800, 13000, 14400, 15000, 15360, 16000, 16384])
 def test_mixed_radix_sizes_match_oracle_and_bluestein(N, torch_dev):
     """Even N <= 16384 with small prime factors (the "round" sizes, the man page's -b 500 among
     them; 2, 3, 5 and -- for the multiples of 100 -- 7 ... 23): LDS mixed-radix kernels (rpf_mixed.hip: the planned kernel for the sizes of
