@@ -126,7 +126,7 @@ def test_non_power_of_two_sizes_match_oracle(N, windowed, torch_dev):
 
 @pytest.mark.parametrize("N", [6, 10, 12, 50, 90, 96, 100, 108, 140, 150, 250, 384, 500, 600, 700, 750, 1000, 1100, 1200, 1300,
                                1458, 1500, 1536, 1700, 1900, 2000, 2300, 2430, 3000, 3600, 3750, 4000, 4050, 4374, 4500, 5000,
-                               5120, 6000, 6250, 6400, 7000, 7500, 7800, 8000, 9000, 9216, 9500, 9720, 9900, 10000, 11000, 12000, 12500, 12800, 13000, 14400, 15000, 15360, 16000, 16384])
+                               5120, 6000, 6250, 6300, 6400, 7000, 7500, 7700, 7800, 8000, 9000, 9216, 9500, 9720, 9900, 10000, 11000, 12000, 12500, 12800, 13000, 14400, 15000, 15360, 16000, 16384])
 def test_mixed_radix_sizes_match_oracle_and_bluestein(N, torch_dev):
     """Even N <= 16384 with small prime factors (the "round" sizes, the man page's -b 500 among
     them; 2, 3, 5 and -- for the multiples of 100 -- 7 ... 23): LDS mixed-radix kernels (rpf_mixed.hip: the planned kernel for the sizes of
@@ -152,7 +152,8 @@ def test_mixed_radix_sizes_match_oracle_and_bluestein(N, torch_dev):
         assert max_rel(got, other) < PARITY
 
 
-@pytest.mark.parametrize("N", [16384, 20000, 24000, 25000, 30000, 32000, 32768, 36000, 40000, 45000, 48000, 50000, 64000, 75000, 80000])
+@pytest.mark.parametrize("N", [14000, 16384, 20000, 21000, 24000, 25000, 30000, 32000, 32768, 35000, 36000, 40000, 45000, 48000,
+                               49000, 50000, 57000, 64000, 75000, 77000, 80000])
 def test_split_mixed_radix_sizes_match_oracle(N, torch_dev):
     """N = P x M (P = 2 ... 5, M <= 16384 one of the planned lengths): the split form of the mixed-radix kernel
     (one workgroup per residue of the spectrum, rpf_mixed.hip) against the float32 oracle, float64 truth and the
@@ -175,18 +176,25 @@ def test_split_mixed_radix_sizes_match_oracle(N, torch_dev):
         assert max_rel(got, o32) < PARITY
         assert max_rel(got, truth_f64(N, stream, R, w)) < VS_TRUTH * 1.5
         assert max_rel(got, other) < PARITY
-        assert max_rel(few, truth_f64(N, stream, 3, w)) < 2 * PARITY      # three frames: little averaging
+        # three frames: little averaging -- the CPU path itself is 1.1 - 1.8e-6 from float64 truth there
+        truth3 = truth_f64(N, stream, 3, w)
+        o3, _ = oracle_accumulate(N, stream, 3, w, 32)
+        assert max_rel(few, truth3) < max(2 * PARITY, 2 * max_rel(o3, truth3))
 
 
 THIN_MARGIN_SIZES = [16384, 20000, 24000, 25000, 30000, 32000, 32768, 36000, 40000, 45000, 48000, 50000, 60000, 64000, 75000,
-                     80000, 131072, 262144, 524288]
+                     80000, 131072, 262144, 524288,
+                     # round 3's split-form sizes (mixed_plans_split.inc, second block)
+                     10500, 11500, 13500, 14000, 17000, 18000, 19000, 21000, 22000, 23000, 26000, 27000, 28000, 33000, 34000,
+                     35000, 38000, 39000, 42000, 44000, 46000, 49000, 51000, 52000, 54000, 55000, 56000, 57000, 63000, 65000,
+                     66000, 68000, 69000, 70000, 72000, 76000, 77000, 78000]
 
 
 @pytest.mark.parametrize("N", THIN_MARGIN_SIZES)
 def test_tone_stream_parity_where_the_margin_is_thin(N, torch_dev):
     """64 frames of the noise + tones stream (the configurations' generator: deterministic lines 1e4 above
     the weakest bins, so a float32 FFT's rounding error is coherent and does not average down) at the
-    sizes whose error against float64 truth sits closest to the bar -- all fifteen split-form sizes and
+    sizes whose error against float64 truth sits closest to the bar -- every split-form size and
     the largest powers of two: GPU against the CPU path, plain per-bin max-rel, windowed and not.
     (The errors are recorded in gpurun_out/fullsize_errors.json -> profiles/r03_fullsize_errors.json.)"""
     import json

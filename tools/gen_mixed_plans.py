@@ -100,6 +100,9 @@ def vgprs(rad, gs, tw):
     return pts + twr + 2 * rad[-1] * gs[-1] + (rad[0] * gs[0] + 1) // 2 + 24
 
 
+SINGLE_SLOT = False      # split form: one frame slot per workgroup whatever the length (several workgroups share a CU)
+
+
 def candidates(n, per_size=18):
     out = _candidates(n, per_size, 0.74) or _candidates(n, per_size, 0.66) or _candidates(n, per_size, 0.5)
     for rad, gs, fpw, tw in EXTRA.get(n, []):
@@ -138,6 +141,8 @@ def _candidates(n, per_size, ratio):
                 best = min(fpws, key=lambda f: abs(f * tmax - target), default=None)
                 if best is not None and best not in pick:
                     pick.append(best)
+            if SINGLE_SLOT:
+                pick = [1] if 60 <= tmax <= 1024 and tmax / (64.0 * -(-tmax // 64)) >= 0.8 else []
             got = False
             for fpw in pick:
                 for tw in TW_MODES:
@@ -180,8 +185,8 @@ EXTRA = {8192: [((16, 8, 8, 8), (2, 4, 4, 4), 1, 2), ((16, 8, 8, 8), (2, 4, 4, 4
 def split_candidates(n):
     """The split form (mixed_split_kernel): n = P x M, P = 2 ... 5, M <= 16384 even -- every single-slot candidate of M
     (search2 rules) with its later passes' twiddles in LDS tables (mode 2, what the split kernel's registers allow)."""
-    global TW_MODES, MAXPPT
-    saved = TW_MODES, MAXPPT
+    global TW_MODES, MAXPPT, SINGLE_SLOT
+    saved = TW_MODES, MAXPPT, SINGLE_SLOT
     TW_MODES, MAXPPT = (0, 1, 2), 32
     out, seen = [], set()
     try:
@@ -189,6 +194,7 @@ def split_candidates(n):
             m = n // p
             if n % p or m % 2 or m > 16384:
                 continue
+            SINGLE_SLOT = m < 4000      # (from 4000 up the plain search's own candidates are single-slot)
             for cost, rad, gs, fpw, tw in candidates(m):
                 key = (p, rad, gs)
                 if fpw != 1 or tw == 1 or len(rad) < 3 or key in seen:
@@ -196,7 +202,7 @@ def split_candidates(n):
                 seen.add(key)
                 out.append((p, m, rad, gs))
     finally:
-        TW_MODES, MAXPPT = saved
+        TW_MODES, MAXPPT, SINGLE_SLOT = saved
     return out
 
 
@@ -209,17 +215,19 @@ def measured_split_rates():
     """(N, P, M, radices, groups) -> Gsample/s of the plain split form, from the committed search results."""
     import ast, re
     rates, n = {}, None
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_split_plan_search.txt")
-    if not os.path.exists(path):
-        return rates
-    for line in open(path):
-        m = re.match(r"N=(\d+)", line)
-        if m:
-            n = int(m.group(1))
+    prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    for name in ("r02_split_plan_search.txt", "r03_split_plan_search.txt"):
+        path = os.path.join(prof, name)
+        if not os.path.exists(path):
             continue
-        m = re.match(r"\s+([\d.]+)\s+\(\S+\)\s+P (\d) M (\d+) (\([\d, ]+\)) (\([\d, ]+\))", line)
-        if m and n:
-            rates[(n, int(m.group(2)), int(m.group(3)), ast.literal_eval(m.group(4)), ast.literal_eval(m.group(5)))] = float(m.group(1))
+        for line in open(path):
+            m = re.match(r"N=(\d+)", line)
+            if m:
+                n = int(m.group(1))
+                continue
+            m = re.match(r"\s+([\d.]+)\s+\(\S+\)\s+P (\d) M (\d+) (\([\d, ]+\)) (\([\d, ]+\))", line)
+            if m and n:
+                rates[(n, int(m.group(2)), int(m.group(3)), ast.literal_eval(m.group(4)), ast.literal_eval(m.group(5)))] = float(m.group(1))
     return rates
 
 
