@@ -25,19 +25,27 @@ def five_smooth(n):
     return n == 1
 
 
-SMOOTH = [n for n in range(6, 10001, 2) if n & (n - 1) and five_smooth(n)] + \
-         [700, 1100, 1300, 1400, 1700, 1900, 2100, 2300, 3500, 4900, 6500, 7000, 7700, 9500, 9900,    # prime radices 7 ... 23
-          11000, 12000, 12500, 12800, 13000, 14400, 15000, 15360, 16000, 16384,                # 32 points per thread
-          20000, 24000, 25000, 30000, 32000, 32768, 36000, 40000, 45000, 48000, 50000, 60000, 64000, 75000, 80000]   # split form
+def table_sizes():
+    """every size of the planned and split-form tables (the library is compiled from them)"""
+    import re
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rtl-power-fftw_amd", "csrc")
+    planned = [int(m) for m in re.findall(r"plan_entry<MixPlan<(\d+),", open(os.path.join(csrc, "mixed_plans.inc")).read())]
+    split = [int(m) for m in re.findall(r"split_entry<.*\(0\),\s+// (\d+)", open(os.path.join(csrc, "mixed_plans_split.inc")).read())]
+    return sorted(set(planned)), sorted(set(split))
+
+
+PLANNED, SPLIT = table_sizes()
+SMOOTH = [n for n in range(6, 10001, 2) if n & (n - 1) and five_smooth(n)] + [n for n in PLANNED if n >= 6000] + SPLIT + SPLIT
+KM_ONLY = bool(os.environ.get("STRESS_KM"))          # STRESS_KM=1: only the mixed-radix tables' sizes
 t0 = time.time()
 ncase = 0
 worst = 0.0
 worst_case = None
 while time.time() - t0 < budget:
-    fam = rng.integers(0, 12)
+    fam = 11 if KM_ONLY else rng.integers(0, 12)
     flags = 0
     if fam >= 10:                                         # LDS mixed-radix kernel (5-smooth, not a power of two)
-        N = int(rng.choice(SMOOTH))
+        N = int(rng.choice(PLANNED + SPLIT + SPLIT)) if KM_ONLY else int(rng.choice(SMOOTH))
         if rng.integers(0, 6) == 0:
             flags = rpf._lib.FLAG_NO_MIXED_RADIX          # the same size through Bluestein
     elif fam < 2:
