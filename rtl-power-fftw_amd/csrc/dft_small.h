@@ -90,6 +90,21 @@ RPF_HD cf cmul_k(cf a, cf w)
 #endif
 }
 
+// acc + a w, w as in cmul_k: two fused multiply-adds -- two roundings per component where cmul_k + add has three
+RPF_HD cf cmac_k(cf acc, cf a, cf w)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    cf d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+        : "=&v"(d)
+        : "v"(a), "s"(w), "v"(acc));
+    return d;
+#else
+    return cf{__builtin_fmaf(-a.y, w.y, __builtin_fmaf(a.x, w.x, acc.x)), __builtin_fmaf(a.x, w.y, __builtin_fmaf(a.y, w.x, acc.y))};
+#endif
+}
+
 // a * W_R^M, M a compile-time constant
 template <int R, int M>
 RPF_HD cf mul_wconst(cf a)

@@ -200,7 +200,7 @@ RPF_HD void mix_split_element(uint32_t raw_i, const float* sgn, float wi, cf wpj
     else if constexpr (WM == 3) x = (f - (kTwo23 + 127.0f)) * wi;
     else x = f * sg - (kTwo23 + 127.0f) * sg;                                       // exact
     if constexpr (FIRST) v[I] = x;
-    else v[I] = v[I] + cmul_k(x, wpj);          // (wpj, mid: the same in every lane -- scalar registers)
+    else v[I] = cmac_k(v[I], x, wpj);           // (wpj, mid: the same in every lane -- scalar registers)
 }
 template <class PL, int WM, bool FIRST, int I = 0>
 RPF_HD void mix_split_accumulate(const uint32_t* raw, const float* sgn, const float* w, cf wpj, cf* v)

@@ -176,10 +176,10 @@ def test_split_mixed_radix_sizes_match_oracle(N, torch_dev):
         assert max_rel(got, o32) < PARITY
         assert max_rel(got, truth_f64(N, stream, R, w)) < VS_TRUTH * 1.5
         assert max_rel(got, other) < PARITY
-        # three frames: little averaging -- the CPU path itself is 1.1 - 1.8e-6 from float64 truth there
-        truth3 = truth_f64(N, stream, 3, w)
-        o3, _ = oracle_accumulate(N, stream, 3, w, 32)
-        assert max_rel(few, truth3) < max(2 * PARITY, 2 * max_rel(o3, truth3))
+        # three frames: little averaging, and a bin that three frames leave almost empty makes any per-bin
+        # relative error large (the CPU path itself is 0.8 - 1.8e-6 from float64 truth there): this run is about
+        # the grid mapping with idle groups, so its error is taken relative to the mean bin (tools/gpu_stress.py's bound)
+        assert max_err_over_mean(few, truth_f64(N, stream, 3, w)) < 3e-6
 
 
 THIN_MARGIN_SIZES = [16384, 20000, 24000, 25000, 30000, 32000, 32768, 36000, 40000, 45000, 48000, 50000, 60000, 64000, 75000,
