@@ -202,6 +202,24 @@ RPF_HD void mix_split_element(uint32_t raw_i, const float* sgn, float wi, cf wpj
     if constexpr (FIRST) v[I] = x;
     else v[I] = cmac_k(v[I], x, wpj);           // (wpj, mid: the same in every lane -- scalar registers)
 }
+// Paired form (P = 2 Q > 5): W_P^{(j+Q) p} = (-1)^p W_P^{j p}, so sections j and j + Q are added first --
+// exactly, the samples being small integers (a windowed pair costs one rounding more) -- and the sum has Q terms:
+// the first pass of a P = 10 split is as accurate as P = 5's.  sp = (-1)^p; wa, wb: the two samples' window values
+// (WM == 2: plain; WM == 0: unused).
+template <class PL, int WM, bool FIRST, int I>
+RPF_HD void mix_split_pair_element(uint32_t raw_a, uint32_t raw_b, const float* sgn, float sp, float wa, float wb, cf wpj, cf* v)
+{
+    static_assert(WM == 0 || WM == 2, "paired form: no window, or window values fetched ahead");
+    constexpr int g = I / PL::R(0), n1 = I % PL::R(0);
+    const float sg = ((n1 * PL::S(0)) & 1) ? -sgn[g] : sgn[g];
+    const cf a = iq_plus_2p23(raw_a) - (kTwo23 + 127.0f);        // exact
+    const cf b = iq_plus_2p23(raw_b) - (kTwo23 + 127.0f);
+    cf x;
+    if constexpr (WM == 2) x = a * (wa * sg) + b * (wb * (sg * sp));
+    else x = (a + b * sp) * sg;                                  // exact: |.| <= 256
+    if constexpr (FIRST) v[I] = x;
+    else v[I] = cmac_k(v[I], x, wpj);
+}
 template <class PL, int WM, bool FIRST, int I = 0>
 RPF_HD void mix_split_accumulate(const uint32_t* raw, const float* sgn, const float* w, cf wpj, cf* v)
 {

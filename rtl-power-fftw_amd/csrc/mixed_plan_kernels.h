@@ -300,6 +300,39 @@ __device__ __forceinline__ void split_sections_rolling(uint32_t* raw, float* wv,
     }
 }
 
+// Paired form (P = 2 Q = 6, 8, 10; mix_split_pair_element): sections j and j + Q ride the one-buffer pipeline side by
+// side -- ra / rb (and wa / wb) hold pair j and are refilled, sample by sample, with pair j + 1 (after the last one:
+// pair 0 of the workgroup's next frame).
+template <class PL, int Q, int WM, bool FIRST, int I = 0>
+__device__ __forceinline__ void split_pair_rolling(uint32_t* ra, uint32_t* rb, float* wa, float* wb, const float* sgn, float sp,
+                                                   cf wpj, cf* v, const uint8_t* na, const float* nw)
+{
+    if constexpr (I < PL::PPT0) {
+        constexpr int T0 = PL::TPF(0), R0 = PL::R(0), S0 = PL::S(0);
+        constexpr int off = (I / R0) * T0 + (I % R0) * S0;
+        mix_split_pair_element<PL, WM, FIRST, I>(ra[I], rb[I], sgn, sp, WM == 2 ? wa[I] : 0.0f, WM == 2 ? wb[I] : 0.0f, wpj, v);
+        ra[I] = *reinterpret_cast<const uint16_t*>(na + 2 * off);
+        rb[I] = *reinterpret_cast<const uint16_t*>(na + 2L * Q * PL::N + 2 * off);
+        if constexpr (WM == 2) {
+            wa[I] = nw[off];
+            wb[I] = nw[Q * PL::N + off];
+        }
+        split_pair_rolling<PL, Q, WM, FIRST, I + 1>(ra, rb, wa, wb, sgn, sp, wpj, v, na, nw);
+    }
+}
+template <class PL, int Q, int WM, int J = 0>
+__device__ __forceinline__ void split_pairs_rolling(uint32_t* ra, uint32_t* rb, float* wa, float* wb, const float* sgn, float sp,
+                                                    const float* w, const cf* wp, cf* v, const uint8_t* frame,
+                                                    const uint8_t* next_frame)
+{
+    if constexpr (J < Q) {
+        const uint8_t* const na = J + 1 < Q ? frame + 2L * (J + 1) * PL::N : next_frame;
+        const float* const nw = J + 1 < Q ? w + (J + 1) * PL::N : w;
+        split_pair_rolling<PL, Q, WM, J == 0>(ra, rb, wa, wb, sgn, sp, wp[J], v, na, nw);
+        split_pairs_rolling<PL, Q, WM, J + 1>(ra, rb, wa, wb, sgn, sp, w, wp, v, frame, next_frame);
+    }
+}
+
 // WM: how a windowed run gets its window values (mix_split_accumulate): 1 = loaded where they are used (every
 // section waits for its loads: one workgroup per CU has nothing else to run meanwhile); 2 = fetched one section
 // ahead, with the raw samples (PPT0 more registers); 3 = window[n] (-1)^n for the whole frame in LDS, filled once
@@ -313,6 +346,9 @@ __global__ __launch_bounds__(PL::WG) void mixed_split_kernel(const uint8_t* __re
     constexpr int M = PL::N, N = P * M, R0 = PL::R(0), G0 = PL::G(0), T0 = PL::TPF(0), S0 = PL::S(0);
     static_assert(WM != 3 || PL::LDS_BYTES + 4 * N <= 160 * 1024, "no room for the window in LDS");
     static_assert(!ROLL || WM != 1, "the rolling pipeline fetches its window values ahead (2) or keeps them in LDS (3)");
+    constexpr bool PAIR = P > 5;             // P = 6, 8, 10: the paired form (split_pairs_rolling), Q = P / 2 terms
+    constexpr int Q = PAIR ? P / 2 : P;
+    static_assert(!PAIR || (P % 2 == 0 && (WM == 0 || WM == 2)), "paired form: even P, window values fetched ahead");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
     // The P workgroups of a frame read the same bytes: put them on one XCD (workgroups go to the 8 XCDs round-robin by
@@ -343,35 +379,40 @@ __global__ __launch_bounds__(PL::WG) void mixed_split_kernel(const uint8_t* __re
 #pragma unroll
         for (int k = 0; k < R0; ++k) tw0[g * R0 + k] = in0 ? twN[(static_cast<long>(ntail) * (p + P * k)) % N] : cf{0.0f, 0.0f};
     }
-    cf wp[P], mid[R0];                                           // the same for every thread of the workgroup
+    cf wp[Q], mid[R0];                                           // the same for every thread of the workgroup
 #pragma unroll
-    for (int j = 0; j < P; ++j) wp[j] = twN[(static_cast<long>(j) * p * M) % N];
+    for (int j = 0; j < Q; ++j) wp[j] = twN[(static_cast<long>(j) * p * M) % N];
+    const float sp = (p & 1) ? -1.0f : 1.0f;                     // (paired form)
 #pragma unroll
     for (int n1 = 0; n1 < R0; ++n1) mid[n1] = twN[(static_cast<long>(n1) * S0 * p) % N];
     double acc[PL::PPTL];
 #pragma unroll
     for (int a = 0; a < PL::PPTL; ++a) acc[a] = 0.0;
 
-    uint32_t raw[ROLL ? 1 : 2][PL::PPT0];          // one sample per register (mix_split_accumulate)
-    float wv[ROLL ? 1 : 2][WM == 2 ? PL::PPT0 : 1];
-    auto load_section0 = [&](long frame, uint32_t* dst, float* wdst) {
-        const uint8_t* const base = stream + (frame < nframes ? frame : nframes - 1) * (2L * N) + 2 * t;
+    uint32_t raw[ROLL && !PAIR ? 1 : 2][PL::PPT0];          // one sample per register (mix_split_accumulate)
+    float wv[ROLL && !PAIR ? 1 : 2][WM == 2 ? PL::PPT0 : 1];
+    auto load_section = [&](long frame, int j, uint32_t* dst, float* wdst) {
+        const uint8_t* const base = stream + (frame < nframes ? frame : nframes - 1) * (2L * N) + 2L * j * M + 2 * t;
 #pragma unroll
         for (int i = 0; i < PL::PPT0; ++i) dst[i] = *reinterpret_cast<const uint16_t*>(base + 2 * ((i / R0) * T0 + (i % R0) * S0));
         if constexpr (WM == 2) {
             // (opaque per frame: otherwise the compiler keeps section 0's values in registers across the loop)
-            const float* w0 = window + t;
+            const float* w0 = window + j * M + t;
             asm volatile("" : "+v"(w0));
 #pragma unroll
             for (int i = 0; i < PL::PPT0; ++i) wdst[i] = w0[(i / R0) * T0 + (i % R0) * S0];
         }
     };
+    auto load_section0 = [&](long frame, uint32_t* dst, float* wdst) { load_section(frame, 0, dst, wdst); };
     const long stride = gridDim.x / P;
     long fb = group;
     // two buffers: section j of a frame lives in raw[j & 1]; the last section's turn puts the next frame's section 0
     // into raw[P & 1] -- for odd P that is raw[1], moved to raw[0] at the top of the next frame (long landed by then)
-    constexpr int B0 = ROLL ? 0 : (P & 1);
-    if (in0) load_section0(fb, raw[B0], wv[B0]);
+    constexpr int B0 = ROLL || PAIR ? 0 : (P & 1);
+    if (in0) {
+        load_section0(fb, raw[B0], wv[B0]);
+        if constexpr (PAIR) load_section(fb, Q, raw[1], wv[1]);
+    }
     __syncthreads();
 #pragma unroll 1
     for (; fb < nframes; fb += stride) {
@@ -383,7 +424,10 @@ __global__ __launch_bounds__(PL::WG) void mixed_split_kernel(const uint8_t* __re
             const float* w = WM == 3 ? wlds + t : window + t;
             if constexpr (WM == 1 || WM == 2) asm volatile("" : "+v"(w));
             const long next = fb + stride;
-            if constexpr (ROLL) {
+            if constexpr (PAIR) {
+                const uint8_t* const next_frame = stream + (next < nframes ? next : nframes - 1) * (2L * N) + 2 * t;
+                split_pairs_rolling<PL, Q, WM>(raw[0], raw[1], wv[0], wv[1], sgn, sp, w, wp, v, frame, next_frame);
+            } else if constexpr (ROLL) {
                 const uint8_t* const next_frame = stream + (next < nframes ? next : nframes - 1) * (2L * N) + 2 * t;
                 split_sections_rolling<PL, P, WM>(raw[0], wv[0], sgn, w, w, wp, v, frame, next_frame);
             } else {
@@ -458,7 +502,7 @@ constexpr PlanEntry plan_entry(int variant)
 template <int P, class PL, int WM = 0, bool ROLL = false>
 constexpr PlanEntry split_entry(int variant)
 {
-    constexpr int wm = WM ? WM : split_window_mode<P, PL>();
+    constexpr int wm = P > 5 ? 2 : WM ? WM : split_window_mode<P, PL>();       // (the paired form fetches its window values ahead)
     return {P * PL::N, variant, split_form<P, PL, 0, ROLL>(), split_form<P, PL, (ROLL && wm == 1) ? 2 : wm, ROLL>()};
 }
 template <int R, int G = 1>

@@ -232,6 +232,18 @@ int run_mixed(const float* window, const uint8_t* stream, long nframes, double* 
     return 0;
 }
 
+// one pair of sections of the paired split form, sample by sample (the kernel: split_pair_rolling)
+template <class PL, bool FIRST, int I = 0>
+void pair_section(bool windowed, const uint32_t* ra, const uint32_t* rb, const float* sgn, float sp, const float* wa,
+                  const float* wb, cf wpj, cf* v)
+{
+    if constexpr (I < PL::PPT0) {
+        if (windowed) rpf::mix_split_pair_element<PL, 2, FIRST, I>(ra[I], rb[I], sgn, sp, wa[I], wb[I], wpj, v);
+        else rpf::mix_split_pair_element<PL, 0, FIRST, I>(ra[I], rb[I], sgn, sp, 0.0f, 0.0f, wpj, v);
+        pair_section<PL, FIRST, I + 1>(windowed, ra, rb, sgn, sp, wa, wb, wpj, v);
+    }
+}
+
 // The split form (N = P M, workgroup p computes X[p + P k] with the M-point plan): pass 0 through
 // mix_unpack_split / mix_butterfly_split, the later passes as above.
 template <class PL, int P>
@@ -260,12 +272,32 @@ int run_mixed_split(const float* window, const uint8_t* stream, long nframes, do
                 cf v[PL::PPT0];
                 float sgn[G0];
                 for (int g = 0; g < G0; ++g) sgn[g] = ((t + g * PL::TPF(0)) & 1) ? -1.0f : 1.0f;
-                for (int j = 0; j < P; ++j) {
-                    uint32_t raw[PL::PPT0];
+                auto load = [&](int j, uint32_t* raw) {
                     for (int i = 0; i < PL::PPT0; ++i) {
                         const int n = rpf::mix_sample_index<PL>(t, i / R0, i % R0) + j * M;
                         raw[i] = frame[2 * n] | (uint32_t)frame[2 * n + 1] << 8;
                     }
+                };
+                if constexpr (P > 5) {          // the paired form: sections j and j + P/2 first (mix_split_pair_element)
+                    constexpr int Q = P / 2;
+                    const float sp = (p & 1) ? -1.0f : 1.0f;
+                    for (int j = 0; j < Q; ++j) {
+                        uint32_t ra[PL::PPT0], rb[PL::PPT0];
+                        float wa[PL::PPT0], wb[PL::PPT0];
+                        load(j, ra);
+                        load(j + Q, rb);
+                        for (int i = 0; i < PL::PPT0; ++i) {
+                            const int n = rpf::mix_sample_index<PL>(t, i / R0, i % R0);
+                            wa[i] = window ? window[n + j * M] : 0.0f;
+                            wb[i] = window ? window[n + (j + Q) * M] : 0.0f;
+                        }
+                        if (j == 0) pair_section<PL, true>(window != nullptr, ra, rb, sgn, sp, wa, wb, wp[j], v);
+                        else pair_section<PL, false>(window != nullptr, ra, rb, sgn, sp, wa, wb, wp[j], v);
+                    }
+                } else
+                for (int j = 0; j < P; ++j) {
+                    uint32_t raw[PL::PPT0];
+                    load(j, raw);
                     const float* w = window ? window + j * M + t : nullptr;
                     if (j == 0) {
                         if (window) rpf::mix_split_accumulate<PL, true, true>(raw, sgn, w, wp[j], v);
@@ -317,6 +349,10 @@ extern "C" int rpf_emul_mixed(int plan, const float* window, const uint8_t* stre
         case 14: return run_mixed_split<MixPlan<1000, 1, 0, MPass<10>, MPass<10>, MPass<10>>, 5>(window, stream, nframes, pwr);
         case 15: return run_mixed_split<MixPlan<600, 1, 0, MPass<25>, MPass<24>>, 3>(window, stream, nframes, pwr);
         case 16: return run_mixed_split<MixPlan<96, 1, 0, MPass<2, 3>, MPass<3, 2>, MPass<4>, MPass<4>>, 4>(window, stream, nframes, pwr);
+        // the paired form (P = 6, 8, 10)
+        case 17: return run_mixed_split<MixPlan<100, 1, 0, MPass<10>, MPass<10>>, 6>(window, stream, nframes, pwr);
+        case 18: return run_mixed_split<MixPlan<96, 1, 0, MPass<2, 3>, MPass<3, 2>, MPass<4>, MPass<4>>, 8>(window, stream, nframes, pwr);
+        case 19: return run_mixed_split<MixPlan<500, 1, 0, MPass<10>, MPass<10>, MPass<5, 2>>, 10>(window, stream, nframes, pwr);
     }
     return -1;
 }
@@ -330,7 +366,8 @@ constexpr ShippedPlan plan_entry(int)
 {
     return {PL::N, &run_mixed<PL>};
 }
-template <int SPLIT, class PL>
+// (window mode and pipeline shape of the kernel's windowed twin: the arithmetic is the same)
+template <int SPLIT, class PL, int WM = 0, bool ROLL = false>
 constexpr ShippedPlan split_entry(int)
 {
     return {SPLIT * PL::N, &run_mixed_split<PL, SPLIT>};
@@ -350,8 +387,8 @@ extern "C" int rpf_emul_shipped(int i, const float* window, const uint8_t* strea
 
 extern "C" int rpf_emul_mixed_n(int plan)
 {
-    const int n[] = {100, 500, 500, 1000, 1200, 300, 3600, 1080, 6000, 96, 700, 2860, 782, 1000, 5000, 1800, 384};
-    return plan >= 0 && plan < 17 ? n[plan] : -1;
+    const int n[] = {100, 500, 500, 1000, 1200, 300, 3600, 1080, 6000, 96, 700, 2860, 782, 1000, 5000, 1800, 384, 600, 768, 5000};
+    return plan >= 0 && plan < 20 ? n[plan] : -1;
 }
 
 // v[k] <- sum_n v[n] W_R^{nk} through dft_small.h (interleaved re, im)

@@ -70,12 +70,13 @@ def test_small_dft_radices(R):
         assert np.abs(np.delete(got, k)).max() < 2e-6 * R
 
 
-@pytest.mark.parametrize("plan", range(17))
+@pytest.mark.parametrize("plan", range(20))
 @pytest.mark.parametrize("windowed", [False, True])
 def test_emulated_mixed_plan_matches_oracle(plan, windowed):
     """mixed_core.h (the planned mixed-radix kernel's per-thread code: element names, padded slots,
     twiddle indices, packed raw samples, bin placement) for two-, three- and four-pass plans with
-    one or several butterflies per thread; plans 13 ... 16 are the split form (N = P x M, P = 2 ... 5)."""
+    one or several butterflies per thread; plans 13 ... 16 are the split form (N = P x M, P = 2 ... 5), 17 ... 19 its
+    paired form (P = 6, 8, 10: sections j and j + P/2 added first)."""
     N = emul_mixed_n(plan)
     R = 12
     stream = rpf.synth.uniform_iq(70 + plan, N * R)

@@ -183,14 +183,14 @@ EXTRA = {8192: [((16, 8, 8, 8), (2, 4, 4, 4), 1, 2), ((16, 8, 8, 8), (2, 4, 4, 4
 
 
 def split_candidates(n):
-    """The split form (mixed_split_kernel): n = P x M, P = 2 ... 5, M <= 16384 even -- every single-slot candidate of M
+    """The split form (mixed_split_kernel): n = P x M, P = 2 ... 5 (6, 8, 10: its paired form), M <= 16384 even -- every single-slot candidate of M
     (search2 rules) with its later passes' twiddles in LDS tables (mode 2, what the split kernel's registers allow)."""
     global TW_MODES, MAXPPT, SINGLE_SLOT
     saved = TW_MODES, MAXPPT, SINGLE_SLOT
     TW_MODES, MAXPPT = (0, 1, 2), 32
     out, seen = [], set()
     try:
-        for p in (2, 3, 4, 5):
+        for p in (2, 3, 4, 5, 6, 8, 10):     # (6, 8, 10: the paired form)
             m = n // p
             if n % p or m % 2 or m > 16384:
                 continue
