@@ -100,7 +100,7 @@ def test_shipped_mixed_radix_plans_are_well_formed():
     for name in ("mixed_plans.inc", "mixed_plans_split.inc"):
         text = open(os.path.join(ROOT, "rtl-power-fftw_amd", "csrc", name)).read().split("#ifdef RPF_TUNING")[0]
         macros = dict(re.findall(r"#define (RPF_M\w+) (MixPlan<.*>)", text))
-        for split, plan, variant in re.findall(r"(?:plan|split)_entry<(?:(\d+), )?(RPF_M\w+|MixPlan<[^()]*>)>\((\d+)\)", text):
+        for split, plan, variant in re.findall(r"(?:plan|split)_entry<(?:(\d+), )?(RPF_M\w+|MixPlan<[^()]*?>)(?:, \d, (?:true|false))?>\((\d+)\)", text):
             plan = macros.get(plan, plan)
             m = re.match(r"MixPlan<(\d+), (\d+), (\d+), (.*)>$", plan)
             assert m, plan
@@ -127,8 +127,8 @@ def test_shipped_mixed_radix_plans_are_well_formed():
             assert (fpw * cpx + table) * 8 <= 160 * 1024, plan
             n = length * int(split or 1)
             if split:
-                assert fpw == 1 and tw != 1 and length % 2 == 0 and 2 <= int(split) <= 5, plan
+                assert fpw == 1 and tw != 1 and length % 2 == 0 and int(split) in (2, 3, 4, 5, 6, 8, 10), plan
             assert n not in seen, n
             seen.add(n)
             assert lib.rpf_supported_n(n) == 1, n
-    assert len(seen) > 150 and {500, 1000, 7000, 10000, 16384, 20000, 32768, 50000} <= seen
+    assert len(seen) > 210 and {500, 1000, 7000, 10000, 14000, 16384, 20000, 32768, 50000, 64000, 80000, 100000, 160000} <= seen

@@ -3,6 +3,9 @@
   python tools/pick_split_plans.py rank  <sweep output> sizes ...   > profiles/rNN_split_plan_search.txt  (ranking, plain runs)
   python tools/pick_split_plans.py plain <sweep output> sizes ...   split_entry lines for mixed_plans_split.inc
   python tools/pick_split_plans.py windowed <sweep output of wincases> <shipped sweep> sizes ...   override lines
+  python tools/pick_split_plans.py both <sweep output, plain and windowed> <shipped sweep> sizes ...
+      plain and windowed picks from one sweep of the splitsearch candidates (each with its default windowed twin) against
+      what ships: table lines for new sizes, override lines where a shipped size gains 5 % or more
 The sweep output is tools/gpu_sweep.py's over `gen_mixed_plans.py splitcases` (resp. `wincases`) of the same sizes.
 Pick: the fastest candidate within LIMIT (5e-7) of float64 truth -- unless one within SOFT (5.5e-7) is 1.5 x faster; no
 candidate within LIMIT: the fastest within FALLBACK (6.5e-7, where the shipped table's least accurate sizes sit), else
@@ -62,6 +65,47 @@ def main():
                 print("    {%d, true, split_form<%d, MixPlan<%d, 1, 2, %s>, %d>()},   // %.0f (%.0f %%) <- %.0f (%.0f %%)"
                       % (n, best[2], best[3], passes(best[4], best[5]), best[6], best[0], 100 * best[0] / plain[0], twin[0],
                          100 * twin[0] / plain[0]))
+        return
+    if mode == "both":
+        shipped = {(n, w): (rate, err) for n, v, w, rate, err in parse(sys.argv[3]) if v == 0}
+        csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rtl-power-fftw_amd", "csrc")
+        in_table = set(int(m) for m in re.findall(r"split_entry<.*\(0\),\s+// (\d+)", open(os.path.join(csrc, "mixed_plans_split.inc")).read()))
+        table, overrides = [], []
+        for n in [int(a) for a in sys.argv[4:]]:
+            cands = g.split_candidates(n)
+            got = {0: [], 1: []}
+            for v, (p, m, rad, gs) in enumerate(cands, start=11 + g.variant_base(n)):
+                for w in (0, 1):
+                    hit = [(rate, err) for nn, vv, ww, rate, err in rows if nn == n and vv == v and ww == w]
+                    if hit:
+                        got[w].append((hit[0][0], hit[0][1], p, m, rad, gs))
+            pick = {w: choose(sorted(got[w], reverse=True)) for w in (0, 1)}
+            if pick[0] is None:
+                print("// %d: no plain candidate within %.1e" % (n, FALLBACK), file=sys.stderr)
+                continue
+            def wm_of(c):      # the default windowed twin of split_entry
+                return 2 if c[2] > 5 else 3 if g.lds_bytes(c[3], c[4], c[5], 1, 2) + 4 * n <= g.LDS_LIMIT else 1
+            new_size = n not in in_table and shipped.get((n, 0), (0, 0))[0] < 0.6 * pick[0][0]
+            if new_size:
+                rate, err, p, m, rad, gs = pick[0]
+                table.append("    split_entry<%d, MixPlan<%d, 1, 2, %s>>(0),   // %d   %.0f (%.1e) <- %.0f"
+                             % (p, m, passes(rad, gs), n, rate, err, shipped.get((n, 0), (0, 0))[0]))
+                if pick[1] and pick[1][2:] != pick[0][2:]:
+                    twin = [c for c in got[1] if c[2:] == pick[0][2:]]
+                    if not twin or pick[1][0] > 1.03 * twin[0][0] or twin[0][1] > FALLBACK:
+                        c = pick[1]
+                        overrides.append("    {%d, true, split_form<%d, MixPlan<%d, 1, 2, %s>, %d>()},   // %.0f (%.1e) <- %.0f"
+                                         % (n, c[2], c[3], passes(c[4], c[5]), wm_of(c), c[0], c[1], twin[0][0] if twin else 0))
+            else:
+                for w in (0, 1):
+                    c, old = pick[w], shipped.get((n, w))
+                    if c and old and c[0] > 1.05 * old[0]:
+                        overrides.append("    {%d, %s, split_form<%d, MixPlan<%d, 1, 2, %s>, %d>()},   // %.0f (%.1e) <- %.0f (%.1e)"
+                                         % (n, "true" if w else "false", c[2], c[3], passes(c[4], c[5]), wm_of(c) if w else 0, c[0], c[1], old[0], old[1]))
+        print("// table lines (mixed_plans_split.inc)")
+        print("\n".join(table))
+        print("// override lines (mixed_plans_override.inc)")
+        print("\n".join(overrides))
         return
     sizes = [int(a) for a in sys.argv[3:]]
     if mode == "rank":
