@@ -230,9 +230,10 @@ int lds_bytes(int N)       // [frame slots][2 buffers + accumulators] + the twid
 
 // Even N served from one workgroup's LDS.  The single source of truth for WHICH sizes is the pair of
 // tables the library is compiled from: mixed_plans.inc (the planned kernel: round sizes with small prime
-// factors up to 16000 bins, and 16384 -- the one power of two K1 cannot hold and the four-step kernels
-// serve at half the rate) and mixed_plans_split.inc (the split form N = P x M, 20000 ... 80000 and 32768);
-// the run-time Stockham kernel takes every other even size up to 5120 bins with prime factors 2, 3, 5 only.
+// factors, and 16384 -- the one power of two K1 cannot hold and the four-step kernels serve at half the
+// rate) and mixed_plans_split.inc (the split form N = P x M); mixed_plans_override.inc moves single runs
+// (plain or windowed) of those sizes onto another form.  The run-time Stockham kernel takes every other
+// even size up to 5120 bins with prime factors 2, 3, 5 only.
 // variant != 0 (tuning build): another plan of the same size; 100 = the Stockham kernel for a size that
 // has a plan.
 #ifdef RPF_TUNING
