@@ -197,35 +197,44 @@ def test_tone_stream_parity_where_the_margin_is_thin(N, torch_dev):
     """64 frames of the noise + tones stream (the configurations' generator: deterministic lines 1e4 above
     the weakest bins, so a float32 FFT's rounding error is coherent and does not average down) at the
     sizes whose error against float64 truth sits closest to the bar -- every split-form size and
-    the largest powers of two: GPU against the CPU path, plain per-bin max-rel, windowed and not.
+    the largest powers of two: GPU against the CPU path, plain per-bin max-rel, windowed and not.  The split
+    form's error depends on the stream by up to 3 x, so its sizes are held to the bar on two streams (the second
+    is the one tools/gpu_parity_score.py scores plan candidates on as well).
     (The errors are recorded in gpurun_out/fullsize_errors.json -> profiles/r03_fullsize_errors.json.)"""
     import json
     import os
     R = 64
-    stream = rpf.synth.noise_tones_iq(300 + N % 89, N * R)
-    out = {}
-    for windowed in (False, True):
-        w = rpf.synth.hann_window(N) if windowed else None
-        with rpf.Datastore(rpf.Params(N=N, window=windowed, repeats=R), w) as ds:
-            got, n = run_device(ds, stream, R, torch_dev)
-        assert n == R
-        o32, _ = oracle_accumulate(N, stream, R, w, 32)
-        truth = truth_f64(N, stream, R, w)
-        out["hann" if windowed else "rect"] = {"gpu_vs_oracle": max_rel(got, o32), "gpu_vs_truth": max_rel(got, truth),
-                                                 "oracle_vs_truth": max_rel(o32, truth)}
+    seeds = [("tone_stream_64_frames", 300 + N % 89)]
+    if N < 131072:
+        seeds.append(("tone_stream_64_frames_second_stream", 1300 + N % 97))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "gpurun_out", "fullsize_errors.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    try:
-        data = json.load(open(path))
-    except Exception:
-        data = {}
-    data.setdefault("tone_stream_64_frames", {})[str(N)] = out
-    json.dump(data, open(path, "w"), indent=1, sort_keys=True)
-    for k, e in out.items():
-        # the bar against the CPU path -- or, where float32 itself gives out (N = 524288: the CPU path is 2.4e-6
-        # from float64 truth on this stream), at least as close to the truth as the CPU path is
-        assert e["gpu_vs_oracle"] < PARITY or e["gpu_vs_truth"] < e["oracle_vs_truth"], (N, k, e)
+    results = []
+    for record, seed in seeds:
+        stream = rpf.synth.noise_tones_iq(seed, N * R)
+        out = {}
+        for windowed in (False, True):
+            w = rpf.synth.hann_window(N) if windowed else None
+            with rpf.Datastore(rpf.Params(N=N, window=windowed, repeats=R), w) as ds:
+                got, n = run_device(ds, stream, R, torch_dev)
+            assert n == R
+            o32, _ = oracle_accumulate(N, stream, R, w, 32)
+            truth = truth_f64(N, stream, R, w)
+            out["hann" if windowed else "rect"] = {"gpu_vs_oracle": max_rel(got, o32), "gpu_vs_truth": max_rel(got, truth),
+                                                     "oracle_vs_truth": max_rel(o32, truth)}
+        try:
+            data = json.load(open(path))
+        except Exception:
+            data = {}
+        data.setdefault(record, {})[str(N)] = out
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+        results.append((record, out))
+    for record, out in results:
+        for k, e in out.items():
+            # the bar against the CPU path -- or, where float32 itself gives out (N = 524288: the CPU path is 2.4e-6
+            # from float64 truth on this stream), at least as close to the truth as the CPU path is
+            assert e["gpu_vs_oracle"] < PARITY or e["gpu_vs_truth"] < e["oracle_vs_truth"], (N, record, k, e)
 
 
 @pytest.mark.parametrize("N", [16384, 32768, 65536, 131072, 262144])
