@@ -189,7 +189,7 @@ THIN_MARGIN_SIZES = [16384, 20000, 24000, 25000, 30000, 32000, 32768, 36000, 400
                      35000, 38000, 39000, 42000, 44000, 46000, 49000, 51000, 52000, 54000, 55000, 56000, 57000, 63000, 65000,
                      66000, 68000, 69000, 70000, 72000, 76000, 77000, 78000,
                      # ... and the paired form's (third block)
-                     81000, 88000, 96000, 98304, 100000, 104000, 105000]
+                     81000, 81920, 88000, 90000, 92000, 96000, 98304, 100000, 104000, 105000, 108000]
 
 
 @pytest.mark.parametrize("N", THIN_MARGIN_SIZES)
