@@ -33,8 +33,8 @@ struct FormOverride {
     bool windowed;
     PlanForm form;
 };
-// rpf_mixed_split.hip: the split form's table (mixed_plans_split.inc; the tuning build's candidates after it) and
-// the overrides
+// rpf_mixed_split.hip: the split form's table (mixed_plans_split.inc; the tuning build's candidates after it);
+// rpf_mixed_override.hip: the overrides
 const PlanEntry* split_plan_table(int* count);
 const FormOverride* form_override_table(int* count);
 
