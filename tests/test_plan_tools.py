@@ -1,0 +1,43 @@
+"""The plan-search tooling (tools/gen_mixed_plans.py, tools/pick_split_plans.py): the candidates it emits are
+well-formed plans of the split form, and the picker applies the rule its header states.  CPU only."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gen_mixed_plans as g          # noqa: E402
+import pick_split_plans as pick      # noqa: E402
+
+
+def test_split_candidates_are_well_formed():
+    for n in (14000, 20000, 6250, 64000, 100000, 98304):
+        cands = g.split_candidates(n)
+        assert cands, n
+        for p, m, rad, gs in cands:
+            assert p in (2, 3, 4, 5, 6, 8, 10) and p * m == n and m % 2 == 0 and m <= 16384
+            prod = 1
+            for r, k in zip(rad, gs):
+                prod *= r
+                assert 2 <= r <= 25 and m % (r * k) == 0 and r * k <= 32
+            assert prod == m and len(rad) >= 3
+            assert max(m // (r * k) for r, k in zip(rad, gs)) <= 1024           # one frame slot per workgroup
+            assert g.lds_bytes(m, rad, gs, 1, 2) <= g.LDS_LIMIT
+
+
+def test_window_candidates_name_a_mode_the_kernel_has():
+    for n in (20000, 50000, 16384):
+        for p, m, rad, gs, wm in g.window_candidates(n):
+            assert wm in (2, 3) and p * m == n
+            if wm == 3:                  # the whole window beside the slab
+                assert g.lds_bytes(m, rad, gs, 1, 2) + 4 * n <= g.LDS_LIMIT
+
+
+def test_picker_rule():
+    fast_inaccurate = (300.0, 9e-7, "a")
+    soft = (290.0, 5.3e-7, "b")
+    ok = (180.0, 4.0e-7, "c")
+    ok_fast = (280.0, 4.9e-7, "d")
+    assert pick.choose([fast_inaccurate, soft, ok]) == soft              # 1.5 x faster within the soft limit
+    assert pick.choose([fast_inaccurate, soft, ok_fast, ok]) == ok_fast  # the fastest within the limit
+    assert pick.choose([fast_inaccurate, (200.0, 6.2e-7, "e")]) == (200.0, 6.2e-7, "e")      # fallback
+    assert pick.choose([fast_inaccurate]) is None

@@ -199,6 +199,8 @@ def split_candidates(n):
                 key = (p, rad, gs)
                 if fpw != 1 or tw == 1 or len(rad) < 3 or key in seen:
                     continue
+                if lds_bytes(m, rad, gs, 1, 2) > LDS_LIMIT:       # (a hand-added candidate whose mode-2 table does not fit)
+                    continue
                 seen.add(key)
                 out.append((p, m, rad, gs))
     finally:
