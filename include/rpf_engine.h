@@ -130,8 +130,9 @@ int rpf_accumulate(rpf_engine* e, const uint8_t* stream, size_t nbytes, int64_t 
  * LDS-DMA staging path, other alignments silently stage through VGPRs).  The
  * engine's device is made current for the call and the caller's restored.  Enqueues the fused kernel and the partial-sum reduce on
  * `hip_stream` (a hipStream_t; NULL = HIP's null stream) and returns
- * without synchronising; d_pwr_out[N] (device doubles) is overwritten with the
- * sum over frames [0, min(repeats, nbytes/(2N))).  Used by bench.py and the
+ * without synchronising; d_pwr_out[N] (device doubles, 16-byte aligned -- the reduce stores
+ * bin pairs -- else RPF_ERR_INVALID_ARGUMENT; the same holds for every d_pwr_out below) is
+ * overwritten with the sum over frames [0, min(repeats, nbytes/(2N))).  Used by bench.py and the
  * full-size parity tests; does not touch the buffer queues. */
 int rpf_accumulate_device(rpf_engine* e, const void* d_stream, size_t nbytes, int64_t repeats,
                           double* d_pwr_out, void* hip_stream, int64_t* repeats_done);

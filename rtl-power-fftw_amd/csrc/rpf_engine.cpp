@@ -863,11 +863,21 @@ static void fill_buffer(uint8_t* dst, const uint8_t* src, size_t n)
     }
     std::vector<std::thread> helpers;
     const size_t share = (n / want + 63) & ~static_cast<size_t>(63);
-    for (size_t t = 1; t < want; ++t) {
-        const size_t lo = t * share, hi = std::min(n, lo + share);
-        if (lo < hi) helpers.emplace_back([=]() { std::memcpy(dst + lo, src + lo, hi - lo); });
+    size_t forked_from = n;          // [0, forked_from) is copied by this thread: its own share, plus what no helper took
+    try {
+        helpers.reserve(want - 1);
+        for (size_t t = want - 1; t >= 1; --t) {      // from the far end, so that what is left over is one run
+            const size_t lo = t * share, hi = std::min(n, lo + share);
+            if (lo < hi) {
+                helpers.emplace_back([=]() { std::memcpy(dst + lo, src + lo, hi - lo); });
+                forked_from = lo;
+            }
+        }
+    } catch (...) {
+        // std::thread could not start (thread limit, out of memory): nothing may leave rpf_accumulate's
+        // extern "C" frame as an exception -- this thread copies the rest itself
     }
-    std::memcpy(dst, src, std::min(n, share));
+    std::memcpy(dst, src, std::min(n, forked_from));
     for (std::thread& h : helpers) h.join();
 }
 
@@ -911,6 +921,8 @@ int rpf_accumulate_device(rpf_engine* e, const void* d_stream, size_t nbytes, in
     if (repeats < 0) return fail(e, RPF_ERR_INVALID_ARGUMENT, "Argument to 'repeats' must be a positive number.");
     if (reinterpret_cast<uintptr_t>(d_stream) & 1)
         return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_accumulate_device: d_stream must be at least 2-byte aligned");
+    if (reinterpret_cast<uintptr_t>(d_pwr_out) & 15)
+        return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_accumulate_device: d_pwr_out must be 16-byte aligned");
     DeviceScope on_device(e->device);
     HIP_TRY(e, on_device.status());
     hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the HIP null stream
@@ -951,6 +963,8 @@ int rpf_device_fused(rpf_engine* e, const void* d_stream, size_t nbytes, int64_t
 int rpf_device_reduce(rpf_engine* e, double* d_pwr_out, void* hip_stream)
 {
     if (!e || !d_pwr_out) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_reduce: NULL argument");
+    if (reinterpret_cast<uintptr_t>(d_pwr_out) & 15)
+        return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_reduce: d_pwr_out must be 16-byte aligned");
     if (e->last_slots < 1 && e->last_hops < 1) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_reduce: nothing to reduce");
     DeviceScope on_device(e->device);
     HIP_TRY(e, on_device.status());
@@ -999,6 +1013,8 @@ int rpf_accumulate_device_hops(rpf_engine* e, const void* const* d_streams, cons
     int rc = check_hops(e, "rpf_accumulate_device_hops", d_streams, nbytes, repeats, n_hops, &frames);
     if (rc != RPF_OK) return rc;
     if (!d_pwr_out) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_accumulate_device_hops: NULL argument");
+    if (reinterpret_cast<uintptr_t>(d_pwr_out) & 15)
+        return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_accumulate_device_hops: d_pwr_out must be 16-byte aligned");
     DeviceScope on_device(e->device);
     HIP_TRY(e, on_device.status());
     hipStream_t s = static_cast<hipStream_t>(hip_stream);

@@ -240,11 +240,12 @@ public:
                 std::unique_lock<std::mutex> lock(mutex);
                 progress.wait(lock, [&]() { return finished_workers_ == G; });
             }
-            if (error.empty()) {
-                reduced.assign(static_cast<size_t>(H) * options_.N, 0.0);
-                if (rpf_scan_reducer_reduce(reducer_, H, reduced.data()) != RPF_OK)
-                    throw RPFexception(rpf_scan_reducer_last_error(reducer_), ReturnValue::HardwareError);
-            }
+            // a failed worker: nothing was reduced, so nothing may be written (the loop below would
+            // otherwise copy hop rows out of the empty `reduced`); JoinAll joins the workers
+            if (!error.empty()) throw RPFexception(error, error_code);
+            reduced.assign(static_cast<size_t>(H) * options_.N, 0.0);
+            if (rpf_scan_reducer_reduce(reducer_, H, reduced.data()) != RPF_OK)
+                throw RPFexception(rpf_scan_reducer_last_error(reducer_), ReturnValue::HardwareError);
         }
         for (int h = 0; h < H && complete; ++h) {
             {

@@ -179,7 +179,11 @@ def test_split_mixed_radix_sizes_match_oracle(N, torch_dev):
         # three frames: little averaging, and a bin that three frames leave almost empty makes any per-bin
         # relative error large (the CPU path itself is 0.8 - 1.8e-6 from float64 truth there): this run is about
         # the grid mapping with idle groups, so its error is taken relative to the mean bin (tools/gpu_stress.py's bound)
-        assert max_err_over_mean(few, truth_f64(N, stream, 3, w)) < 3e-6
+        few_truth = truth_f64(N, stream, 3, w)
+        assert max_err_over_mean(few, few_truth) < 3e-6
+        # ... and per bin wherever the bin is not nearly empty, so that a regression on a sparse set of bins shows
+        filled = few_truth > 0.1 * few_truth.mean()
+        assert max_rel(few[filled], few_truth[filled]) < 2 * PARITY
 
 
 THIN_MARGIN_SIZES = [16384, 20000, 24000, 25000, 30000, 32000, 32768, 36000, 40000, 45000, 48000, 50000, 60000, 64000, 75000,
@@ -193,23 +197,22 @@ THIN_MARGIN_SIZES = [16384, 20000, 24000, 25000, 30000, 32000, 32768, 36000, 400
 
 
 @pytest.mark.parametrize("N", THIN_MARGIN_SIZES)
-def test_tone_stream_parity_where_the_margin_is_thin(N, torch_dev):
+def test_tone_stream_parity_where_the_margin_is_thin(N, torch_dev, tmp_path):
     """64 frames of the noise + tones stream (the configurations' generator: deterministic lines 1e4 above
     the weakest bins, so a float32 FFT's rounding error is coherent and does not average down) at the
     sizes whose error against float64 truth sits closest to the bar -- every split-form size and
     the largest powers of two: GPU against the CPU path, plain per-bin max-rel, windowed and not.  The split
     form's error depends on the stream by up to 3 x, so its sizes are held to the bar on two streams (the second
-    is the one tools/gpu_parity_score.py scores plan candidates on as well).
-    (The errors are recorded in gpurun_out/fullsize_errors.json -> profiles/r03_fullsize_errors.json.)"""
+    is the one tools/gpu_parity_score.py scores plan candidates on as well).  These are the streams the plans were
+    PICKED on; the held-out streams are test_gpu_heldout.py's.
+    (The errors are recorded in the file $RPF_PARITY_RECORD names -> profiles/r04_fullsize_errors.json; without it
+    in pytest's tmp_path.)"""
     import json
-    import os
     R = 64
     seeds = [("tone_stream_64_frames", 300 + N % 89)]
     if N < 131072:
         seeds.append(("tone_stream_64_frames_second_stream", 1300 + N % 97))
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "gpurun_out", "fullsize_errors.json")
-    os.makedirs(os.path.dirname(path), exist_ok=True)
+    path = os.environ.get("RPF_PARITY_RECORD") or str(tmp_path / "fullsize_errors.json")
     results = []
     for record, seed in seeds:
         stream = rpf.synth.noise_tones_iq(seed, N * R)
@@ -232,9 +235,13 @@ def test_tone_stream_parity_where_the_margin_is_thin(N, torch_dev):
         results.append((record, out))
     for record, out in results:
         for k, e in out.items():
-            # the bar against the CPU path -- or, where float32 itself gives out (N = 524288: the CPU path is 2.4e-6
-            # from float64 truth on this stream), at least as close to the truth as the CPU path is
-            assert e["gpu_vs_oracle"] < PARITY or e["gpu_vs_truth"] < e["oracle_vs_truth"], (N, record, k, e)
+            # the bar against the CPU path.  N = 524288 only: float32 itself gives out there (the CPU path is 2.4e-6
+            # from float64 truth on this stream; test_gpu_heldout.py has the documented limit test) -- at least as
+            # close to the truth as the CPU path is
+            if N == 524288:
+                assert e["gpu_vs_oracle"] < PARITY or e["gpu_vs_truth"] < e["oracle_vs_truth"], (N, record, k, e)
+            else:
+                assert e["gpu_vs_oracle"] < PARITY, (N, record, k, e)
 
 
 @pytest.mark.parametrize("N", [16384, 32768, 65536, 131072, 262144])

@@ -12,7 +12,7 @@ import rtl_power_fftw_amd as rpf
 from helpers import ROOT, PlanParams, dp, fp, oracle_lib
 
 HOST_DIR = os.path.join(ROOT, "rtl-power-fftw_amd", "host")
-CLI = os.path.join(HOST_DIR, "rpf_power")
+CLI = os.environ.get("RPF_POWER_CLI") or os.path.join(HOST_DIR, "rpf_power")   # (tools/gpu_tsan.sh: the sanitised build)
 
 
 @pytest.fixture(scope="module")

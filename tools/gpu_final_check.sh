@@ -6,7 +6,9 @@ ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/final
 mkdir -p $OUT
 cd $ROOT
-timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest.log
+rm -f $OUT/fullsize_errors.json
+export RPF_PARITY_RECORD=$OUT/fullsize_errors.json      # the parity tests' measured errors -> profiles/rNN_fullsize_errors.json
+timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
 timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/bench_20.json 2> $OUT/bench_20.err; echo "bench rc=$?"; cut -c1-400 $OUT/bench_20.json
 cd /tmp && export TMPDIR=/tmp
