@@ -470,11 +470,6 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         return fail(nullptr, RPF_ERR_INVALID_ARGUMENT,
                     "Number of bins must be a positive even number.");
     const int variant = static_cast<int>((cfg->flags >> 8) & 0xffu);
-#ifndef RPF_TUNING
-    if (cfg->flags & RPF_FLAG_FOURSTEP_FUSED)
-        return fail(nullptr, RPF_ERR_INVALID_ARGUMENT,
-                    "RPF_FLAG_FOURSTEP_FUSED: the fused four-step kernel exists only in the tuning build of this library.");
-#endif
     // (asking for the fused four-step kernel is asking for the four-step path)
     const bool mixed = rpf::mixed_supported(cfg->N, variant) &&
                        !(cfg->flags & (RPF_FLAG_NO_MIXED_RADIX | RPF_FLAG_FOURSTEP_FUSED));

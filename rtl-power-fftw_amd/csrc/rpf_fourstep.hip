@@ -270,100 +270,143 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_rows_kernel(const cf* __restr
 }
 
 
-#ifdef RPF_TUNING   // the fused persistent four-step kernel: exact, measured slower -- lab equipment
-// ---- fused four-step: the intermediate never leaves the XCD's L2 ----------------------------
-// K2a/K2b above exchange Y through HBM: 8 B written + 8 B read per sample against 2 algorithmic
-// bytes, and the pair runs at the speed of that traffic.  Here ONE persistent kernel does both
-// steps and the exchange stays on chip: the workgroups that share an XCD (one per CU, found by
-// HW_REG_XCC_ID, so correctness never rests on a block -> XCD guess) form a team that owns a round
-// of FR = 262144 / N frames at a time -- N * FR * 8 B = 2 MB of Y, half the XCD's 4 MB L2:
-//     phase A  every member transforms one tile of 16 * SUBA columns and parks the twiddled result
-//              in LDS; once the team has finished READING the previous round's Y (barrier 2) it
-//              writes its rows of Y with plain stores -- the lines stay dirty in the team's L2;
-//     barrier 1 (team-wide: one arrival counter per XCD, relaxed agent-scope polls)
-//     phase B  every member loads one tile of 16 * SUBB rows with sc1 loads (served by the L2, never
-//              by this CU's L1, which other CUs' stores do not refresh), transforms and accumulates.
-// Same-L2 producers and consumers need no release/acquire fences (no buffer_wbl2 / buffer_inv):
-// a store is in the L2 once vmcnt says so, and the L2 is the point of coherence inside an XCD.
-// Every spin is bounded; a team that does not assemble (a CU busy with someone else's kernel, an
-// unexpected XCD population) raises ctl->abort, everybody leaves, and K3 poisons the spectrum with
-// NaN -- loud, never wrong.  The engine proves the path once at creation and otherwise keeps K2a/K2b.
+// ---- fused four-step: the intermediate is read back from the writing XCD's L2 --------------------
+// K2a/K2b above exchange Y through the fabric: 8 B written + 8 B read per sample against 2 algorithmic bytes,
+// and the pair runs at the speed of that traffic.  What the L2 offers (profiles/r04_l2_residency.txt):
+// every stored byte still leaves it (write-through), but a line stored by one CU is served to another CU OF THE
+// SAME XCD from the L2 -- the read half of the round trip can stay on chip.  Here ONE persistent launch does both
+// steps: the 32 workgroups that share an XCD (one per CU, found by HW_REG_XCC_ID: correctness never rests on a
+// block -> XCD guess) form a team that owns one round of FR = 262144 / N frames at a time, 2 MB of Y, double
+// buffered in the team's 4 MB L2.  Inside a workgroup the sixteen wavefronts split into two ROLES that run their
+// own loops and never meet at an s_barrier (role barriers are LDS counters), so that the memory phases of one
+// role hide behind the arithmetic of the other:
+//     producers (waves 0-7)   raw rows of the workgroup's 16 * SUBA columns -> LDS (dword LDS-DMA, a round ahead);
+//                             two column groups per wave: N1-point transforms, times W_N^{n2 k1} (the columns of a
+//                             workgroup never change: the step twiddles and the window are per-lane REGISTERS,
+//                             loaded once -- no table traffic beside Y in the L2), through the wave's slab into
+//                             natural k1 order, plain 16-byte stores into buffer (round & 1) once the team has
+//                             finished reading round - 2 out of it; drain; `produced` += 1.
+//     consumers (waves 8-15)  wait for the team's 32 arrivals on `produced`; the [N2][16 * SUBB] tile of the
+//                             round comes in with sc1 loads (served by the L2, never by this CU's L1, which other
+//                             CUs' stores do not refresh); `consumed` += 1; two row groups per wave: N2-point
+//                             transforms, |X|^2 into f64 register accumulators that live for the whole launch.
+// The counters are touched only by atomics that execute in the XCD's L2.  Every spin is bounded; a team that does
+// not assemble (a CU busy with someone else's kernel, an unexpected XCD population) raises ctl->abort, everybody
+// leaves, and K3's companion kernel NaN-fills the spectrum -- loud, never wrong.  The engine proves the path once
+// at creation and otherwise keeps K2a/K2b.
 struct FusedCtl {
     unsigned arrivals[8][32];     // [xcd][0]: members registered (own 128-byte line each)
-    unsigned barrier[8][32];      // [xcd][0]: monotonically increasing arrival count
+    // One counter per buffer (round parity): a cumulative count over all rounds would let a workgroup that is a round
+    // ahead stand in for one that is a round behind (31 arrivals of round j + 1 of round j + 1 = 32).  Two rounds
+    // ahead is impossible: writing buffer p again needs all 32 consumers of its previous round.
+    unsigned produced[8][2][32];  // [xcd][parity][0]: producer arrivals, 32 per round of that parity
+    unsigned consumed[8][2][32];  // [xcd][parity][0]: consumer arrivals
     unsigned registered[32];      // [0]: workgroups registered, grid-wide
     unsigned abort[32];           // [0]: != 0 -> results invalid
 };
-constexpr unsigned kSpinLimit = 4u << 20;      // polls of ~0.1 us: ~0.5 s
+constexpr unsigned kSpinLimit = 4u << 20;      // global polls of ~0.1-3 us: >= 0.5 s
+constexpr unsigned kLdsSpinLimit = 1u << 26;   // LDS polls of ~50 ns
 
 __device__ __forceinline__ unsigned ctl_load(const unsigned* p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Team barrier in two halves.  arrive: every thread's global stores are in the L2 (vmcnt) and
-// its loads have returned before thread 0 counts the workgroup in.  wait: thread 0 polls the
-// team's counter (bounded), everybody else parks at the workgroup barrier.
-// Current value of a counter by way of a returning atomic add of zero, written in assembly: the
-// compiler turns `fetch_add(p, 0)` at workgroup scope into a plain (sc0) load, which the CU's L1
-// serves -- stale for ever once the line is resident.  An atomic always executes in the L2.
-__device__ __forceinline__ unsigned l2_atomic_read(unsigned* p)
+// Current value of a team counter: an sc1 load, written in assembly, is served by the XCD's L2 -- where the team's
+// atomics execute -- and never by this CU's L1 (a plain or sc0 load is, stale for ever once the line is resident).
+// Round 2 polled with a returning atomic add of zero: 64 pollers per XCD saturate the one L2 channel that owns the
+// counter's line (~88 atomics per microsecond), and every stream that stripes over the channels -- the Y stores'
+// drain, the tile loads -- then runs at that channel's pace (measured: 94 us per round instead of < 10).
+__device__ __forceinline__ unsigned l2_read(const unsigned* p)
 {
     unsigned r;
-    const unsigned zero = 0;
-    asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p), "v"(zero) : "memory");
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
     return r;
 }
 
-// The team's counter is only ever touched by read-modify-write atomics WITHOUT the sc1 bit
-// (workgroup scope in the language): they execute in the XCD's L2, which all members share --
-// an L2 round trip per poll instead of a trip to the memory-side coherence point.
-__device__ __forceinline__ void team_arrive(FusedCtl* ctl, int xcd)
+// What the two roles of a workgroup share in LDS (static: the dynamic area is full).
+struct FusedSync {
+    unsigned bar[2];          // role barriers: monotonically increasing arrival counts (8 per barrier)
+    unsigned seen[2][2];      // [0][parity]: `consumed` as last polled by the producers' wave 0; [1][parity]: `produced`, consumers'
+    unsigned abort;           // a bounded spin ran out somewhere in this workgroup (or the grid's flag was seen)
+    int team[3];              // xcd, rank, ok
+};
+
+// Barrier among the 8 waves of one role (no s_barrier: that one spans both roles).  `target` = 8 x the number of
+// this role's barriers so far.  LDS operations of one wave execute in order, so the arrival follows its writes.
+__device__ __forceinline__ bool role_barrier(FusedSync* sy, int role, unsigned target, int lane)
 {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0)
-        __hip_atomic_fetch_add(&ctl->barrier[xcd][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ bool team_wait(FusedCtl* ctl, int xcd, unsigned target, int* ok_flag)
-{
-    if (threadIdx.x == 0) {
-        unsigned spins = 0;
-        int ok = 1;
-        while (l2_atomic_read(&ctl->barrier[xcd][0]) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > kSpinLimit || ((spins & 1023u) == 0 && ctl_load(&ctl->abort[0]) != 0)) {
-                __hip_atomic_store(&ctl->abort[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
-                break;
-            }
-        }
-        *ok_flag = ok;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(&sy->bar[role], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    unsigned spins = 0;
+    while (__hip_atomic_load(&sy->bar[role], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kLdsSpinLimit || __hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
     }
-    __syncthreads();
-    const bool ok = *ok_flag != 0;
-    __syncthreads();            // ok_flag may be rewritten by the next wait
-    return ok;
+    return true;
 }
 
-// -DRPF_FUSED_PROFILE: thread 0 of every workgroup adds the cycles it spends in each segment of a
-// round to g_fused_prof (tools/gpu_fused_profile.py prints them); never in the shipped library.
+// Wait until the team's counter reaches `target`: wave 0 of the role polls the L2 (one lane), everybody else
+// watches the value it publishes in LDS.
+__device__ __forceinline__ bool team_wait(FusedCtl* ctl, FusedSync* sy, const unsigned* counter, unsigned* seen, unsigned target,
+                                          bool poller, int lane)
+{
+    if (__hip_atomic_load(seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) return true;
+    unsigned spins = 0;
+    if (poller) {
+        for (;;) {
+            const unsigned v = __builtin_amdgcn_readfirstlane(l2_read(counter));
+            if (v >= target) {
+                if (lane == 0) __hip_atomic_store(seen, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return true;
+            }
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > kSpinLimit || __hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ||
+                ((spins & 255u) == 0 && ctl_load(&ctl->abort[0]) != 0)) {
+                if (lane == 0) {
+                    __hip_atomic_store(&ctl->abort[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&sy->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                return false;
+            }
+        }
+    }
+    while (__hip_atomic_load(seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kLdsSpinLimit || __hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
+    }
+    return true;
+}
+
+// -DRPF_FUSED_PROFILE: lane 0 of wave 0 of each role adds the wall-clock ticks (100 MHz) it spends in each segment
+// of a round to g_fused_prof (tools/gpu_fused_profile.py prints them); never in the shipped library.
 #ifdef RPF_FUSED_PROFILE
-__device__ unsigned long long g_fused_prof[10];
+__device__ unsigned long long g_fused_prof[16];
 struct FusedClock {
-    unsigned long long last, sum[10];
-    __device__ __forceinline__ void start() { for (int i = 0; i < 10; ++i) sum[i] = 0; last = __builtin_readcyclecounter(); }
-    __device__ __forceinline__ void stamp(int i) { const unsigned long long now = __builtin_readcyclecounter(); sum[i] += now - last; last = now; }
-    __device__ __forceinline__ void publish() { if (threadIdx.x == 0) { for (int i = 0; i < 9; ++i) atomicAdd(&g_fused_prof[i], sum[i]); atomicAdd(&g_fused_prof[9], 1ull); } }
+    unsigned long long last, sum[8];
+    __device__ __forceinline__ void start() { for (int i = 0; i < 8; ++i) sum[i] = 0; last = wall_clock64(); }
+    __device__ __forceinline__ void stamp(int i) { const unsigned long long now = wall_clock64(); sum[i] += now - last; last = now; }
+    __device__ __forceinline__ void publish(int base, bool who) { if (who) { for (int i = 0; i < 7; ++i) atomicAdd(&g_fused_prof[base + i], sum[i]); atomicAdd(&g_fused_prof[base + 7], 1ull); } }
 };
 #define FSTAMP(i) fclk.stamp(i)
 #else
 struct FusedClock {
     __device__ __forceinline__ void start() {}
-    __device__ __forceinline__ void publish() {}
+    __device__ __forceinline__ void publish(int, bool) {}
 };
 #define FSTAMP(i) ((void)0)
 #endif
+
+constexpr int kRoleWaves = kWaves / 2, kRoleThreads = kRoleWaves * 64;
+
+template <class S>
+constexpr int fused_lds_bytes()
+{
+    constexpr int slabs = kRoleWaves * (S::SLAB_A + S::SLAB_B) * (int)sizeof(cf);
+    constexpr int raw = S::N1 * (16 * S::SUBA / 2 + 1) * 4;
+    constexpr int tile = S::N2 * S::ROW_PITCH * (int)sizeof(cf);
+    return slabs + tile + raw;
+}
 
 template <class S, bool WINDOW, bool DMA>
 __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* __restrict__ stream, int nframes,
@@ -378,23 +421,25 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
     using GB = typename S::GB;
     constexpr int N1 = S::N1, N2 = S::N2, N = S::N;
     constexpr int TA = GA::T, TB = GB::T, P = 8;
-    constexpr int TPF = N / 8192;                   // tiles per frame (both phases)
+    constexpr int TPF = N / 8192;                   // tiles per frame (both steps)
     constexpr int FR = 32 / TPF;                    // frames per round
-    constexpr int COLS = 16 * S::SUBA;              // columns per phase-A tile
+    constexpr int COLS = 16 * S::SUBA;              // columns per workgroup and round
     constexpr int PITCH = COLS / 2 + 1;             // dwords per staged raw row (odd: conflict-free column reads)
-    static_assert(TPF >= 1 && TPF <= 32 && N2 / COLS == TPF && N1 / S::ROW_TILE == TPF, "tile counts");
+    constexpr int GROUPS = 2;                       // column / row groups per wave: 16 groups over 8 waves
+    constexpr int RT = S::ROW_TILE, HALF = RT / 2;
+    static_assert(TPF >= 1 && TPF <= 32 && N2 / COLS == TPF && N1 / RT == TPF, "tile counts");
+    static_assert(fused_lds_bytes<S>() <= 160 * 1024 - 64, "LDS");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int SLAB_CPX = (S::SLAB_A > S::SLAB_B ? S::SLAB_A : S::SLAB_B);
-    cf* const slabs = reinterpret_cast<cf*>(smem);                                     // [16][SLAB_CPX]
-    unsigned char* const area = smem + kWaves * SLAB_CPX * sizeof(cf);
-    cf* const tile = reinterpret_cast<cf*>(area);                                      // [N2][ROW_PITCH]
-    uint8_t* const raw = area + N2 * S::ROW_PITCH * sizeof(cf);                        // [N1][PITCH] dwords: its own
-    // region, so that the next round's rows can be staged (LDS-DMA) while phase B works on the tile
-    __shared__ int team[4];
+    cf* const slabsA = reinterpret_cast<cf*>(smem);                                    // [8][SLAB_A]
+    cf* const slabsB = slabsA + kRoleWaves * S::SLAB_A;                                // [8][SLAB_B]
+    cf* const tile = slabsB + kRoleWaves * S::SLAB_B;                                  // [N2][ROW_PITCH]
+    uint8_t* const raw = reinterpret_cast<uint8_t*>(tile + N2 * S::ROW_PITCH);         // [N1][PITCH] dwords
+    __shared__ FusedSync sync_;
+    FusedSync* const sy = &sync_;
 
     const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 
     // ---- team assembly -------------------------------------------------------------------------
     if (tid == 0) {
@@ -411,183 +456,233 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
         for (int x = 0; ok && x < 8; ++x)
             if (ctl_load(&ctl->arrivals[x][0]) != 32u) ok = 0;
         if (!ok) __hip_atomic_store(&ctl->abort[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        team[0] = xcd;
-        team[1] = static_cast<int>(rank);
-        team[2] = ok;
+        sy->team[0] = xcd;
+        sy->team[1] = static_cast<int>(rank);
+        sy->team[2] = ok;
+        sy->bar[0] = sy->bar[1] = 0;
+        sy->seen[0][0] = sy->seen[0][1] = sy->seen[1][0] = sy->seen[1][1] = 0;
+        sy->abort = 0;
     }
-    __syncthreads();
-    const int xcd = team[0], rank = team[1];
-    if (!team[2] || rank >= 32) return;
+    __syncthreads();                                 // the only workgroup-wide barrier before the output stage
+    const int xcd = sy->team[0], rank = sy->team[1];
+    if (!sy->team[2] || rank >= 32) return;
     const int fsl = rank / TPF, tl = rank % TPF;            // frame slot of the round, tile of the frame
-    cf* const Y = Yall + static_cast<size_t>(xcd) * FR * N + static_cast<size_t>(fsl) * N;
-
-    // Per-lane constants are re-derived at the top of every round from an opaque copy of the thread
-    // index: hoisted out of the loop they (and every address built from them) would stay live across
-    // both phases and spill at 128 VGPRs.  For the same reason the sub-transform twiddles are
-    // (re)loaded per phase -- ahead of the barrier wait that precedes their use.
-    double acc[P];
-#pragma unroll
-    for (int a = 0; a < P; ++a) acc[a] = 0.0;
-
-    // raw rows of (frame f, tile tl) -> LDS, asynchronously (LDS-DMA) when DMA
-    auto stage_rows = [&](int f, int tid_) {
-        const uint8_t* const frame = stream + static_cast<size_t>(f) * (2 * N);
-#pragma unroll 1
-        for (int i = 0; i < (N1 * PITCH + kWG - 1) / kWG; ++i) {
-            const int L = i * kWG + tid_;
-            const int rr = L / PITCH, d = L % PITCH;
-            if (L < N1 * PITCH && d < COLS / 2) {
-                const uint8_t* src = frame + 2 * (static_cast<size_t>(N2) * rr + COLS * tl) + 4 * d;
-                if constexpr (DMA) {
-                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(raw + 4 * (i * kWG + wave * 64)), 4, 0, 0);
-                } else {
-                    const uint16_t lo = *reinterpret_cast<const uint16_t*>(src);
-                    const uint16_t hi = *reinterpret_cast<const uint16_t*>(src + 2);
-                    *reinterpret_cast<uint32_t*>(raw + 4 * L) = lo | (static_cast<uint32_t>(hi) << 16);
-                }
-            }
-        }
-    };
-    if (xcd * FR + fsl < nframes && xcd < (nframes + FR - 1) / FR) stage_rows(xcd * FR + fsl, tid);
-
     const int nrounds = (nframes + FR - 1) / FR;
-    FusedClock fclk;
-    fclk.start();
-    unsigned bar = 0;                                        // team barriers passed so far
-#pragma unroll 1
-    for (int r = xcd; r < nrounds; r += 8) {
-        const int f = r * FR + fsl;
-        const bool valid = f < nframes;
-        int tid_ = tid;
-        asm volatile("" : "+v"(tid_));
-        const int lane = tid_ & 63;
-        const int subA = lane / TA, tA = lane % TA, subB = lane / TB, tB = lane % TB;
-        cf* const slabA = slabs + wave * SLAB_CPX + subA * GA::LDS_CPX;
-        cf* const slabB = slabs + wave * SLAB_CPX + subB * GB::LDS_CPX;
-        const int cl = wave * S::SUBA + subA;                   // this lane group's column inside the tile
-        const int c = COLS * tl + cl;                           // n2
-        const float sgn = (c & 1) ? -1.0f : 1.0f;               // (-1)^n, n = N2 n1 + n2
-        const float off = -(kTwo23 + 127.0f) * sgn;
-        const int jrow = wave * S::SUBB + subB;                 // this lane group's row inside the tile
+    const int nj = xcd < nrounds ? (nrounds - xcd + 7) / 8 : 0;    // this team's rounds: xcd, xcd + 8, ...
+    cf* const Yteam = Yall + static_cast<size_t>(xcd) * 2 * FR * N + static_cast<size_t>(fsl) * N;   // + (j & 1) * FR * N
 
-        // ---- phase A: columns of tile tl -> LDS slabs (natural k1 order) ------------------------
-        // (this round's raw rows were staged ahead: before the loop, or during the previous phase B)
-        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        FSTAMP(0);                       // raw rows staged
-        if (valid) {
-            cf twA[GA::NPASS - 1][P - 1];
-            load_twiddles<GA, 1>(tA, tw_n1, twA);
-            cf x[P];
+    const bool producer = wave < kRoleWaves;
+    const int rw = wave & (kRoleWaves - 1);          // wave inside its role
+    const int rtid = rw * 64 + lane;                 // thread inside its role
+    bool alive = true;
+    FusedClock fclk;
+
+    double acc[GROUPS][P];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g)
+#pragma unroll
+        for (int a = 0; a < P; ++a) acc[g][a] = 0.0;
+
+    if (producer) {
+        // ================================ producers: columns ====================================
+        const int sub = lane / TA, t = lane % TA;
+        cf* const slab = slabsA + rw * S::SLAB_A + sub * GA::LDS_CPX;
+        cf tw[GA::NPASS - 1][P - 1];
+        load_twiddles<GA, 1>(t, tw_n1, tw);
+        // this lane's columns never change: inter-step twiddles (and window) once, into registers
+        cf wstep[GROUPS][P];
+        float wsgn[WINDOW ? GROUPS : 1][P];
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            const int c = COLS * tl + (rw * GROUPS + g) * S::SUBA + sub;
 #pragma unroll
             for (int a = 0; a < P; ++a) {
-                const int n1 = tA + TA * a;
-                const uint32_t iq =
-                    *reinterpret_cast<const uint16_t*>(raw + 4 * (n1 * PITCH + (cl >> 1)) + 2 * (cl & 1));
-                const cf v = iq_plus_2p23(iq);
-                if constexpr (WINDOW) {
-                    const float w = window[static_cast<size_t>(c) * N1 + n1] * sgn;
-                    x[a] = (v - (kTwo23 + 127.0f)) * w;
-                } else {
-                    x[a] = v * sgn + off;
+                wstep[g][a] = twN[static_cast<size_t>(c) * N1 + TA * a + t];
+                if constexpr (WINDOW) wsgn[g][a] = window[static_cast<size_t>(c) * N1 + t + TA * a] * ((c & 1) ? -1.0f : 1.0f);
+            }
+        }
+        // raw rows of (frame f, tile tl) -> LDS, asynchronously (LDS-DMA) when DMA
+        auto stage_rows = [&](int f) {
+            const uint8_t* const frame = stream + static_cast<size_t>(f) * (2 * N);
+#pragma unroll 1
+            for (int i = 0; i < (N1 * PITCH + kRoleThreads - 1) / kRoleThreads; ++i) {
+                const int L = i * kRoleThreads + rtid;
+                const int rr = L / PITCH, d = L % PITCH;
+                if (L < N1 * PITCH && d < COLS / 2) {
+                    const uint8_t* src = frame + 2 * (static_cast<size_t>(N2) * rr + COLS * tl) + 4 * d;
+                    if constexpr (DMA) {
+                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(raw + 4 * (i * kRoleThreads + rw * 64)), 4, 0, 0);
+                    } else {
+                        const uint16_t lo = *reinterpret_cast<const uint16_t*>(src);
+                        const uint16_t hi = *reinterpret_cast<const uint16_t*>(src + 2);
+                        *reinterpret_cast<uint32_t*>(raw + 4 * L) = lo | (static_cast<uint32_t>(hi) << 16);
+                    }
                 }
             }
-            // the inter-step twiddles of this column: issued now, used after the transform
-            cf wstep[P];
-#pragma unroll
-            for (int a = 0; a < P; ++a)          // read once per round: streamed past the L2 (nt), Y keeps its lines
-                wstep[a] = __builtin_nontemporal_load(twN + static_cast<size_t>(c) * N1 + TA * a + tA);
-            group_fft<GA>(tA, x, twA, slabA);
-            exchange_sync<false>();
-#pragma unroll
-            for (int a = 0; a < P; ++a) {
-                const int k1 = bin_of<GA>(tA, a);
-                slabA[GA::slot(k1)] = cmul(x[a], wstep[a]);
-            }
-            exchange_sync<false>();
-        }
-        // ---- wait: the team has finished READING the previous round's Y (arrivals posted after
-        // each member's tile load below); trivially true in the first round ------------------------
-        FSTAMP(1);                       // column transforms
-        if (bar > 0 && !team_wait(ctl, xcd, bar * 32u, &team[3])) return;
-        FSTAMP(2);                       // wait: previous Y read by everybody
-        if (valid) {
-            cf* const yrow = Y + static_cast<size_t>(c) * N1;
-#pragma unroll
-            for (int a = 0; a < P / 2; ++a) {
-                const int e = 2 * tA + 2 * TA * a;
-                cf4 v;
-                v.lo = slabA[GA::slot(e)];
-                v.hi = slabA[GA::slot(e + 1)];
-                *reinterpret_cast<cf4*>(yrow + e) = v;
-            }
-        }
-        // ---- barrier 1: the round's Y is complete in the team's L2 --------------------------------
-        team_arrive(ctl, xcd);
-        FSTAMP(3);                       // Y rows written (stores drained)
-        cf twB[GB::NPASS - 1][P - 1];   // issued ahead of the wait they hide behind
-        load_twiddles<GB, 1>(tB, tw_n2, twB);
-        if (!team_wait(ctl, xcd, ++bar * 32u, &team[3])) return;
-        FSTAMP(4);                       // barrier 1
-        // ---- phase B: rows of tile tl ---------------------------------------------------------------
-        if (valid) {
-            const cf* const yt = Y + S::ROW_TILE * tl;
-            // sc1 loads: served by the L2, never by this CU's L1 (other CUs wrote these lines);
-            // 16 bytes per lane, all of a thread's loads in flight before the first use
-            constexpr int PERB = N2 * S::ROW_TILE / kWG / 2;
-            typedef float f4 __attribute__((ext_vector_type(4)));
-            f4 v[PERB];
-#pragma unroll
-            for (int i = 0; i < PERB; ++i) {
-                const int idx = i * kWG + tid_;
-                const int n2 = idx / (S::ROW_TILE / 2), j = 2 * (idx % (S::ROW_TILE / 2));
-                const cf* src = yt + static_cast<size_t>(n2) * N1 + j;
-                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[i]) : "v"(src) : "memory");
-            }
+        };
+        if (nj > 0 && xcd * FR + fsl < nframes) stage_rows(xcd * FR + fsl);
+        unsigned nbar = 0;
+        fclk.start();
+#pragma unroll 1
+        for (int j = 0; j < nj && alive; ++j) {
+            const int f = (xcd + 8 * j) * FR + fsl;
+            const bool valid = f < nframes;
+            // this round's raw rows (staged a round ahead) have landed, for every producer wave
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;
+            FSTAMP(0);                       // raw rows staged
+            cf* const Yf = Yteam + static_cast<size_t>(j & 1) * FR * N;
 #pragma unroll
-            for (int i = 0; i < PERB; ++i) {
-                const int idx = i * kWG + tid_;
-                const int n2 = idx / (S::ROW_TILE / 2), j = 2 * (idx % (S::ROW_TILE / 2));
-                // (the "+v" ties each value to the wait above: the loads are opaque to the compiler)
-                asm volatile("" : "+v"(v[i]));
-                tile[n2 * S::ROW_PITCH + j] = cf{v[i].x, v[i].y};
-                tile[n2 * S::ROW_PITCH + j + 1] = cf{v[i].z, v[i].w};
+            for (int g = 0; g < GROUPS; ++g) {
+                const int cl = (rw * GROUPS + g) * S::SUBA + sub;       // this lane group's column inside the tile
+                const int c = COLS * tl + cl;                           // n2
+                if (valid) {
+                    const float sgn = (c & 1) ? -1.0f : 1.0f;           // (-1)^n, n = N2 n1 + n2
+                    const float off = -(kTwo23 + 127.0f) * sgn;
+                    cf x[P];
+#pragma unroll
+                    for (int a = 0; a < P; ++a) {
+                        const int n1 = t + TA * a;
+                        const uint32_t iq =
+                            *reinterpret_cast<const uint16_t*>(raw + 4 * (n1 * PITCH + (cl >> 1)) + 2 * (cl & 1));
+                        const cf v = iq_plus_2p23(iq);
+                        if constexpr (WINDOW) x[a] = (v - (kTwo23 + 127.0f)) * wsgn[g][a];
+                        else x[a] = v * sgn + off;
+                    }
+                    group_fft<GA>(t, x, tw, slab);
+                    exchange_sync<false>();
+#pragma unroll
+                    for (int a = 0; a < P; ++a) slab[GA::slot(bin_of<GA>(t, a))] = cmul(x[a], wstep[g][a]);
+                    exchange_sync<false>();
+                }
+                // the buffer held round j - 2: the team has finished reading it (trivially true in rounds 0, 1)
+                if (g == 0) {
+                    FSTAMP(1);                   // first column group transformed
+                    if (j >= 2 && !(alive = team_wait(ctl, sy, &ctl->consumed[xcd][j & 1][0], &sy->seen[0][j & 1], 32u * (j / 2),
+                                                      rw == 0, lane))) break;
+                    FSTAMP(2);                   // wait: buffer free
+                }
+                if (valid) {
+                    cf* const ycol = Yf + static_cast<size_t>(c) * RT;      // tile-major, like K2a
+#pragma unroll
+                    for (int a = 0; a < P / 2; ++a) {
+                        const int e = 2 * t + 2 * TA * a;
+                        cf4 v;
+                        v.lo = slab[GA::slot(e)];
+                        v.hi = slab[GA::slot(e + 1)];
+                        *reinterpret_cast<cf4*>(ycol + static_cast<size_t>(e / RT) * (N2 * RT) + e % RT) = v;
+                    }
+                    exchange_sync<false>();
+                }
             }
+            if (!alive) break;
+            FSTAMP(3);                       // second group transformed, Y stores issued
+            // every producer wave is done with the raw rows: stage the next round's behind the stores
+            if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;
+            if (j + 1 < nj && f + 8 * FR < nframes) stage_rows(f + 8 * FR);
+            // the round's rows of Y are in the L2 once this wave's stores have drained; the last wave to get
+            // there counts the workgroup in (the next round's top-of-loop barrier would do, but a round late)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FSTAMP(4);                       // stores drained (+ next raw rows landed)
+            if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;
+            if (rw == 0 && lane == 0)
+                __hip_atomic_fetch_add(&ctl->produced[xcd][j & 1][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            FSTAMP(5);
         }
-        team_arrive(ctl, xcd);          // this member is done with Y (its tile is in LDS)
-        ++bar;
-        FSTAMP(5);                       // Y tile loaded
-        // next round's raw rows: in flight while the rows are transformed
-        if (r + 8 < nrounds && (r + 8) * FR + fsl < nframes) stage_rows((r + 8) * FR + fsl, tid_);
-        if (valid) {
-            cf x[P];
+        fclk.publish(0, rw == 0 && lane == 0);
+    } else {
+        // ================================ consumers: rows =======================================
+        const int sub = lane / TB, t = lane % TB;
+        cf* const slab = slabsB + rw * S::SLAB_B + sub * GB::LDS_CPX;
+        cf tw[GB::NPASS - 1][P - 1];
+        load_twiddles<GB, 1>(t, tw_n2, tw);
+        constexpr int PERB = N2 * RT / kRoleThreads / 2;     // 16-byte loads per thread and tile
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        unsigned nbar = 0;
+        fclk.start();
+#pragma unroll 1
+        for (int j = 0; j < nj && alive; ++j) {
+            const int f = (xcd + 8 * j) * FR + fsl;
+            const bool valid = f < nframes;
+            if (!(alive = team_wait(ctl, sy, &ctl->produced[xcd][j & 1][0], &sy->seen[1][j & 1], 32u * (j / 2 + 1), rw == 0, lane))) break;
+            FSTAMP(0);                       // wait: round produced
+            if (valid) {
+                const cf* const yt = Yteam + static_cast<size_t>(j & 1) * FR * N + static_cast<size_t>(tl) * (N2 * RT);
+                // sc1 loads: served by the L2, never by this CU's L1 (other CUs wrote these lines); 16 bytes per lane,
+                // all eight of a thread's loads in flight -- and the wait for them in the SAME asm statement: the
+                // compiler does not know that an asm load's destination is written when the data returns, and is free
+                // to copy or reuse it before a separate s_waitcnt (tools/l2_residency_bench.hip met exactly that)
+                f4 v[PERB];
+                static_assert(PERB == 8, "the tile is 8192 complex values");
+                const cf* src[PERB];
 #pragma unroll
-            for (int a = 0; a < P; ++a) x[a] = tile[(tB + TB * a) * S::ROW_PITCH + jrow];
-            group_fft<GB>(tB, x, twB, slabB);
-            phase_accumulate(x, acc, P);
-            exchange_sync<false>();
+                for (int i = 0; i < PERB; ++i) src[i] = yt + 2 * (i * kRoleThreads + rtid);
+                asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
+                             "global_load_dwordx4 %1, %9, off sc1\n\t"
+                             "global_load_dwordx4 %2, %10, off sc1\n\t"
+                             "global_load_dwordx4 %3, %11, off sc1\n\t"
+                             "global_load_dwordx4 %4, %12, off sc1\n\t"
+                             "global_load_dwordx4 %5, %13, off sc1\n\t"
+                             "global_load_dwordx4 %6, %14, off sc1\n\t"
+                             "global_load_dwordx4 %7, %15, off sc1\n\t"
+                             "s_waitcnt vmcnt(0)"
+                             : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                             : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(src[5]), "v"(src[6]), "v"(src[7])
+                             : "memory");
+#pragma unroll
+                for (int i = 0; i < PERB; ++i) {
+                    const int idx = i * kRoleThreads + rtid;
+                    cf* const dst = tile + (idx / HALF) * S::ROW_PITCH + 2 * (idx % HALF);
+                    dst[0] = cf{v[i].x, v[i].y};
+                    dst[1] = cf{v[i].z, v[i].w};
+                }
+            }
+            FSTAMP(1);                       // tile loaded
+            if (!(alive = role_barrier(sy, 1, (nbar += kRoleWaves), lane))) break;
+            // every consumer wave's loads have returned: the team may overwrite this buffer (round j + 2)
+            if (rw == 0 && lane == 0)
+                __hip_atomic_fetch_add(&ctl->consumed[xcd][j & 1][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            FSTAMP(2);
+            if (valid) {
+#pragma unroll
+                for (int g = 0; g < GROUPS; ++g) {
+                    const int jrow = (rw * GROUPS + g) * S::SUBB + sub;
+                    cf x[P];
+#pragma unroll
+                    for (int a = 0; a < P; ++a) x[a] = tile[(t + TB * a) * S::ROW_PITCH + jrow];
+                    group_fft<GB>(t, x, tw, slab);
+                    phase_accumulate(x, acc[g], P);
+                    exchange_sync<false>();
+                }
+            }
+            FSTAMP(3);                       // rows transformed
+            // the tile is rewritten next round: every consumer wave has read its columns
+            if (!(alive = role_barrier(sy, 1, (nbar += kRoleWaves), lane))) break;
+            FSTAMP(4);
         }
-        __syncthreads();        // tile/slabs are reused by the next round's phase A
-        FSTAMP(6);                       // row transforms + accumulate
+        fclk.publish(8, rw == 0 && lane == 0);
     }
-    fclk.publish();
 
     // ---- partial spectrum of (team, frame slot): rows of tile tl ---------------------------------------
-    __syncthreads();
-    const int lane = tid & 63;
-    const int subB = lane / TB, tB = lane % TB;
-    const int jrow = wave * S::SUBB + subB;
-    double* const stage = reinterpret_cast<double*>(smem);                          // [N2 k2][ROW_PITCH]
+    __syncthreads();                                 // (waves that gave up have left: the barrier does not wait for them)
+    if (__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
+    double* const stage = reinterpret_cast<double*>(tile);                            // [N2 k2][ROW_PITCH]
+    if (!producer) {
+        const int sub = lane / TB, t = lane % TB;
 #pragma unroll
-    for (int a = 0; a < P; ++a) stage[bin_of<GB>(tB, a) * S::ROW_PITCH + jrow] = acc[a];
-    __syncthreads();
-    double* const out = partial + (static_cast<size_t>(xcd) * FR + fsl) * N + S::ROW_TILE * tl;
+        for (int g = 0; g < GROUPS; ++g) {
+            const int jrow = (rw * GROUPS + g) * S::SUBB + sub;
 #pragma unroll
-    for (int i = 0; i < N2 * S::ROW_TILE / kWG; ++i) {
+            for (int a = 0; a < P; ++a) stage[bin_of<GB>(t, a) * S::ROW_PITCH + jrow] = acc[g][a];
+        }
+    }
+    __syncthreads();
+    double* const out = partial + (static_cast<size_t>(xcd) * FR + fsl) * N + RT * tl;
+#pragma unroll
+    for (int i = 0; i < N2 * RT / kWG; ++i) {
         const int idx = i * kWG + tid;
-        const int k2 = idx / S::ROW_TILE, j = idx % S::ROW_TILE;
-        out[static_cast<size_t>(k2) * N1 + j] = stage[k2 * S::ROW_PITCH + j];
+        const int k2 = idx / RT, jr = idx % RT;
+        out[static_cast<size_t>(k2) * N1 + jr] = stage[k2 * S::ROW_PITCH + jr];
     }
 }
 
@@ -602,11 +697,11 @@ __global__ void fused_poison_kernel(const FusedCtl* __restrict__ ctl, double* __
 #ifdef RPF_FUSED_PROFILE
 }  // namespace
 }  // namespace rpf
-extern "C" int rpf_debug_fused_profile(unsigned long long* out10, int reset)
+extern "C" int rpf_debug_fused_profile(unsigned long long* out16, int reset)
 {
-    if (hipMemcpyFromSymbol(out10, HIP_SYMBOL(rpf::g_fused_prof), sizeof(unsigned long long) * 10) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rpf::g_fused_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
     if (reset) {
-        unsigned long long z[10] = {0};
+        unsigned long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(rpf::g_fused_prof), z, sizeof z);
     }
     return 0;
@@ -615,7 +710,6 @@ namespace rpf {
 namespace {
 #endif
 
-#endif  // RPF_TUNING
 
 // Large Bluestein path: even N in (4096, 131072] that is not a power of two,
 // M = M1 x M2 = 2^ceil(log2(2N-1)) (bluestein_tables.h has the identity):
@@ -730,9 +824,7 @@ using ColsFn = void (*)(const uint8_t*, int, const cf*, const cf*, const float*,
 using MidFn = void (*)(const cf*, int, const cf*, const cf*, const cf*, cf*);
 using RowsFn = void (*)(const cf*, int, const cf*, double*, int);
 
-#ifdef RPF_TUNING
 using FusedFn = void (*)(const uint8_t*, int, const cf*, const cf*, const cf*, const float*, cf*, double*, FusedCtl*);
-#endif
 using RowsTableFn = void (*)(const cf*, size_t, size_t, int, std::vector<cf>&);
 using ColsTableFn = void (*)(const cf*, int, std::vector<cf>&);
 
@@ -741,22 +833,9 @@ struct SplitInfo {
     ColsFn cols[2][2];   // [window][dma]
     RowsFn rows;
     RowsTableFn step_twiddles;   // W_N^{n2 k1} in K2a's lane order
-#ifdef RPF_TUNING
     FusedFn fused[2][2];         // [window][dma]
     int fused_lds, fused_fr;     // LDS bytes; frames per team round
-#endif
 };
-
-#ifdef RPF_TUNING
-template <class S>
-constexpr int fused_lds_bytes()
-{
-    constexpr int slab = (S::SLAB_A > S::SLAB_B ? S::SLAB_A : S::SLAB_B) * kWaves * (int)sizeof(cf);
-    constexpr int raw = S::N1 * (16 * S::SUBA / 2 + 1) * 4;
-    constexpr int tile = S::N2 * S::ROW_PITCH * (int)sizeof(cf);
-    return slab + tile + raw;
-}
-#endif
 
 template <int N1, int N2>
 SplitInfo make_split()
@@ -766,12 +845,9 @@ SplitInfo make_split()
                      {{fourstep_cols_kernel<S, false, false>, fourstep_cols_kernel<S, false, true>},
                       {fourstep_cols_kernel<S, true, false>, fourstep_cols_kernel<S, true, true>}},
                      fourstep_rows_kernel<S, true>, lane_ordered_rows<typename S::GA>,
-#ifdef RPF_TUNING
                      {{fourstep_fused_kernel<S, false, false>, fourstep_fused_kernel<S, false, true>},
                       {fourstep_fused_kernel<S, true, false>, fourstep_fused_kernel<S, true, true>}},
-                     fused_lds_bytes<S>(), 262144 / S::N
-#endif
-    };
+                     fused_lds_bytes<S>(), 262144 / S::N};
 }
 
 const SplitInfo kSplits[] = {
@@ -918,12 +994,11 @@ hipError_t launch_fourstep(int N, bool window, bool use_dma, const uint8_t* d_st
     return hipSuccess;
 }
 
-#ifdef RPF_TUNING
 // ---- fused four-step -----------------------------------------------------------
-size_t fourstep_fused_scratch_bytes(int N)       // Y of one round per XCD: 8 x 2 MB
+size_t fourstep_fused_scratch_bytes(int N)       // Y of two rounds per XCD: 8 x 2 x 2 MB
 {
     const SplitInfo* s = find_split(N);
-    return s ? sizeof(cf) * static_cast<size_t>(s->N) * s->fused_fr * 8 : 0;
+    return s ? sizeof(cf) * static_cast<size_t>(s->N) * s->fused_fr * 8 * 2 : 0;
 }
 int fourstep_fused_slots(int N)
 {
@@ -990,19 +1065,6 @@ hipError_t fourstep_fused_aborted(const void* d_ctl, hipStream_t stream, bool* a
     return hipSuccess;
 }
 
-#else   // the shipped library has no fused kernel: asking for it fails rpf_engine_create
-size_t fourstep_fused_scratch_bytes(int) { return 0; }
-int fourstep_fused_slots(int) { return 0; }
-size_t fourstep_fused_ctl_bytes() { return 0; }
-hipError_t fourstep_fused_prepare(int, int, int*) { return hipErrorNotSupported; }
-hipError_t launch_fourstep_fused(int, bool, bool, const uint8_t*, long, const cf*, const cf*, const cf*, const float*, cf*,
-                                 double*, void*, hipStream_t)
-{
-    return hipErrorNotSupported;
-}
-hipError_t launch_fused_poison(const void*, double*, int, hipStream_t) { return hipErrorNotSupported; }
-hipError_t fourstep_fused_aborted(const void*, hipStream_t, bool*) { return hipErrorNotSupported; }
-#endif
 
 // ---- large Bluestein path --------------------------------------------------
 bool bigblu_supported(int N) { return find_blu_split(N) != nullptr; }

@@ -275,13 +275,7 @@ def test_fused_four_step_equals_the_two_kernel_path(N, torch_dev):
     frame, only the grouping of the f64 partial sums differs.  Frame counts that leave teams and
     frame slots idle, several launches back to back on one engine (stale L2 lines, counters)."""
     import torch
-    if "tuning" not in os.path.basename(rpf._lib.lib_path()):
-        # the shipped library has no fused kernel: asking for it must fail loudly, never fall back
-        with pytest.raises(rpf.RPFError) as err:
-            rpf.Datastore(rpf.Params(N=N, repeats=8), flags=rpf._lib.FLAG_FOURSTEP_FUSED)
-        assert err.value.returnValue() == rpf.ReturnValue.InvalidArgument
-        return
-    R = 3 * (262144 // N) * 8 + 5                    # a few full rounds and a ragged tail
+    R = 5 * (262144 // N) * 8 + 5                    # a few full rounds and a ragged tail
     stream = rpf.synth.uniform_iq(17 + N % 31, N * R)
     d_in = torch.from_numpy(stream).to(torch_dev)
     w = rpf.synth.hann_window(N) + np.float32(0.25)

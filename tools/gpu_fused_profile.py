@@ -12,14 +12,15 @@ dev = torch.device("cuda:0")
 d_in = rpf.synth.noise_tones_iq_torch(4, N * R, dev)
 d_out = torch.zeros(N, dtype=torch.float64, device=dev)
 s = torch.cuda.current_stream().cuda_stream
-names = ["stage raw", "column FFTs", "wait prev Y read", "Y write+drain", "barrier 1", "Y tile load", "row FFTs+acc"]
+names = ["P wait raw rows", "P first column group", "P wait buffer free", "P second group + stores", "P drain + next raw", "P role barrier + arrive", "-",
+         "C wait produced", "C tile load", "C role barrier + arrive", "C row FFTs + acc", "C role barrier", "-", "-"]
 for flags, label in ((rpf._lib.FLAG_FOURSTEP_FUSED, "fused"), (0, "two-kernel")):
     with rpf.Datastore(rpf.Params(N=N, repeats=R), flags=flags) as ds:
         lib = ds._lib
         for _ in range(3):
             ds.accumulate_device(d_in.data_ptr(), 2 * N * R, R, d_out.data_ptr(), s)
         torch.cuda.synchronize()
-        prof = (ctypes.c_ulonglong * 10)()
+        prof = (ctypes.c_ulonglong * 16)()
         if hasattr(lib, "rpf_debug_fused_profile"):
             lib.rpf_debug_fused_profile(prof, 1)
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -32,10 +33,12 @@ for flags, label in ((rpf._lib.FLAG_FOURSTEP_FUSED, "fused"), (0, "two-kernel"))
         print("%s: %.3f ms per %d frames = %.1f Gsample/s" % (label, ms, R, N * R / ms / 1e6))
         if flags and hasattr(lib, "rpf_debug_fused_profile"):
             lib.rpf_debug_fused_profile(prof, 1)
-            wgs = max(1, prof[9])
             rounds = (R * N // 262144 + 7) // 8
-            tot = sum(prof[i] for i in range(7))
-            print("  per workgroup and round (%d rounds per team), cycles:" % rounds)
-            for i, n in enumerate(names):
-                print("   %-18s %8.0f  (%4.1f %%)" % (n, prof[i] / wgs / rounds, 100.0 * prof[i] / max(1, tot)))
-            print("   total %.0f cycles per round" % (tot / wgs / rounds))
+            for base, role in ((0, "producers"), (8, "consumers")):
+                wgs = max(1, prof[base + 7])
+                tot = sum(prof[base + i] for i in range(7))
+                print("  %s, per workgroup and round (%d rounds per team), microseconds:" % (role, rounds))
+                for i in range(7):
+                    if names[(base and 7) + i] != "-":
+                        print("   %-26s %8.3f  (%4.1f %%)" % (names[(base and 7) + i], prof[base + i] / wgs / rounds / 100.0, 100.0 * prof[base + i] / max(1, tot)))
+                print("   total %.3f us per round" % (tot / wgs / rounds / 100.0))

@@ -8,10 +8,16 @@ BIN=$GRAFT_REPO_ROOT/tools/l2_residency_bench
 [ -x $BIN ] || hipcc --offload-arch=gfx950 -O3 $GRAFT_REPO_ROOT/tools/l2_residency_bench.hip -o $BIN
 cd /tmp && export TMPDIR=/tmp
 ROUNDS=${1:-1000}
-timeout 300 $BIN $ROUNDS > $OUT/timing.txt 2>&1
+timeout 120 $BIN $ROUNDS > $OUT/timing.txt 2>&1
+rc=$?
 cat $OUT/timing.txt
+if [ $rc -ne 0 ]; then
+  echo "timing run failed (rc=$rc): variants one by one, 100 rounds"
+  for v in 0 1 2 3 4 5 6 7 8; do timeout 30 $BIN 100 $v 2>&1 | grep -v "^#" | cut -c1-200; done
+  exit 1
+fi
 for c in FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o l2 -- $BIN $ROUNDS > $OUT/$c.log 2>&1
+  timeout 120 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o l2 -- $BIN $ROUNDS > $OUT/$c.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, re

@@ -7,8 +7,8 @@
 //   tools/gpu_l2_residency.sh                     # the same under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 //
 // One persistent launch, one 256-thread workgroup per CU (96 KB of LDS requested so that no two share a CU).
-// The workgroups that find themselves on one XCD (HW_REG_XCC_ID) form a team: ranks 0-11 write, 12-23 read,
-// 24-31 either idle or stream a "foreign" 2 MB table through the same L2 (what the 2 MB W_N table did to the
+// The workgroups that find themselves on one XCD (HW_REG_XCC_ID) form a team: ranks 0-7 write, 8-15 read,
+// 16-23 either idle or stream a "foreign" 2 MB table through the same L2 (what the 2 MB W_N table did to the
 // round-2 fused kernel).  Per round: writers store the team's buffer (16 B per lane, pattern = f(round, index)),
 // drain (s_waitcnt vmcnt(0)), arrive on the team's `produced` counter; readers wait for all writers, apply the
 // acquire under test, read the whole buffer with 8 x 16 B loads in flight per lane, count words that do not
@@ -26,8 +26,15 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-constexpr int kWriters = 12, kReaders = 12;
+constexpr int kWriters = 8, kReaders = 8;
 constexpr unsigned kSpinLimit = 1u << 22;
+#ifndef POLL_ATOMICS
+#define POLL_ATOMICS 0
+#endif
+constexpr bool kPollWithAtomics = POLL_ATOMICS;   // -DPOLL_ATOMICS=1: poll with returning atomic adds of zero (hot-spots one L2 channel)
+#ifndef POLL_SLEEP
+#define POLL_SLEEP 8
+#endif
 
 struct Ctl {
     unsigned members[8][32];     // [xcd][0]: workgroups registered on that XCD
@@ -35,8 +42,8 @@ struct Ctl {
     unsigned consumed[8][32];    // [xcd][0]
     unsigned registered[32];
     unsigned abort_[32];
-    unsigned long long stale[32];
-    unsigned long long cycles[32];   // [0]: sum over readers of cycles spent loading; [1]: writers storing
+    unsigned long long stale[256];   // per workgroup (team rank + 32 x xcd): words read that were not this round's
+    unsigned long long ticks[256];   // per workgroup: 100 MHz ticks spent storing + draining (writers) / loading (readers)
 };
 
 enum StoreKind { ST_PLAIN, ST_NT, ST_SC1, ST_SC0SC1 };
@@ -52,12 +59,25 @@ __device__ __forceinline__ void store16(u4* p, u4 v)
     else if constexpr (K == ST_SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
     else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
 }
+// Eight 16-byte loads in flight and the wait for them in ONE asm statement: the compiler does not know that an
+// asm load's destination is written later, when the data returns -- given the chance it copies or reuses those
+// registers before a separate s_waitcnt (seen here as a memory aperture violation: an address register overwritten
+// by a returning load).
+#define LOAD8(FLAVOUR)                                                                                                   \
+    asm volatile("global_load_dwordx4 %0, %8, off" FLAVOUR "\n\tglobal_load_dwordx4 %1, %9, off" FLAVOUR                  \
+                 "\n\tglobal_load_dwordx4 %2, %10, off" FLAVOUR "\n\tglobal_load_dwordx4 %3, %11, off" FLAVOUR           \
+                 "\n\tglobal_load_dwordx4 %4, %12, off" FLAVOUR "\n\tglobal_load_dwordx4 %5, %13, off" FLAVOUR           \
+                 "\n\tglobal_load_dwordx4 %6, %14, off" FLAVOUR "\n\tglobal_load_dwordx4 %7, %15, off" FLAVOUR           \
+                 "\n\ts_waitcnt vmcnt(0)"                                                                                \
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]) \
+                 : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])                \
+                 : "memory")
 template <int K>
-__device__ __forceinline__ void load16(u4& v, const u4* p)
+__device__ __forceinline__ void load8(u4 (&v)[8], const u4* const (&p)[8])
 {
-    if constexpr (K == LD_SC1) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    else if constexpr (K == LD_SC0SC1) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
-    else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (K == LD_SC1) LOAD8(" sc1");
+    else if constexpr (K == LD_SC0SC1) LOAD8(" sc0 sc1");
+    else LOAD8("");
 }
 
 // AGENT: the counter is shared with another XCD (CROSS rows): the atomic must execute at the memory-side
@@ -67,8 +87,15 @@ __device__ __forceinline__ unsigned l2_atomic_read(unsigned* p)
 {
     unsigned r;
     const unsigned zero = 0;
-    if constexpr (AGENT) asm volatile("global_atomic_add %0, %1, %2, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p), "v"(zero) : "memory");
-    else asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p), "v"(zero) : "memory");
+    if (kPollWithAtomics) {
+        if constexpr (AGENT) asm volatile("global_atomic_add %0, %1, %2, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p), "v"(zero) : "memory");
+        else asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p), "v"(zero) : "memory");
+    } else {
+        // an sc1 load is served by the L2 (never by this CU's L1), where the team's atomics execute; for a counter
+        // another XCD updates (AGENT) sc0 sc1 goes to the memory-side coherence point
+        if constexpr (AGENT) asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+        else asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+    }
     return r;
 }
 template <bool AGENT>
@@ -78,7 +105,7 @@ __device__ __forceinline__ bool wait_for(unsigned* ctr, unsigned target, Ctl* ct
         unsigned spins = 0;
         int ok = 1;
         while (l2_atomic_read<AGENT>(ctr) < target) {
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(POLL_SLEEP);
             if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(&ctl->abort_[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 __hip_atomic_store(&ctl->abort_[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
@@ -112,7 +139,7 @@ __device__ __forceinline__ u4 pattern(unsigned round, unsigned idx)
 // bytes: the team's buffer (a multiple of 4096); buf: 8 such buffers 16 MB apart; table: 8 x 2 MB foreign tables.
 template <int ST, int LD, bool FOREIGN, bool CROSS>
 __global__ __launch_bounds__(256) void residency_kernel(u4* __restrict__ buf, size_t bytes, int rounds,
-                                                        const u4* __restrict__ table, Ctl* __restrict__ ctl, unsigned* sink)
+                                                        const u4* __restrict__ table, Ctl* __restrict__ ctl, unsigned* sink, int stage)
 {
     extern __shared__ unsigned char smem[];
     __shared__ int team[4];
@@ -133,11 +160,11 @@ __global__ __launch_bounds__(256) void residency_kernel(u4* __restrict__ buf, si
         team[0] = xcd;
         team[1] = static_cast<int>(rank);
         team[2] = ok;
-        reinterpret_cast<volatile unsigned char*>(smem)[0] = 0;     // the LDS request is real
+        smem[0] = 0;                                                // the LDS request is real
     }
     __syncthreads();
     const int xcd = team[0], rank = team[1];
-    if (!team[2]) return;
+    if (!team[2] || stage == 0) return;
     constexpr size_t kTeamStride = (16u << 20) / 16;               // in 16-byte units
     u4* const mine = buf + kTeamStride * xcd;
     const u4* const theirs = buf + kTeamStride * (CROSS ? (xcd + 1) % 8 : xcd);
@@ -152,7 +179,7 @@ __global__ __launch_bounds__(256) void residency_kernel(u4* __restrict__ buf, si
     if (rank < kWriters) {
         unsigned long long cyc = 0;
         for (int r = 0; r < rounds; ++r) {
-            if (r > 0 && !wait_for<CROSS>(consumed, static_cast<unsigned>(kReaders) * r, ctl, &team[3])) return;
+            if (stage >= 2 && r > 0 && !wait_for<CROSS>(consumed, static_cast<unsigned>(kReaders) * r, ctl, &team[3])) return;
             const unsigned long long t0 = wall_clock64();
             for (int c = rank; c < nchunks; c += kWriters) {
                 const unsigned idx = static_cast<unsigned>(c) * 256u + tid;
@@ -161,39 +188,41 @@ __global__ __launch_bounds__(256) void residency_kernel(u4* __restrict__ buf, si
             arrive<CROSS>(produced);
             cyc += wall_clock64() - t0;
         }
-        if (tid == 0) atomicAdd(&ctl->cycles[1], cyc);
-    } else if (rank < kWriters + kReaders) {
+        if (tid == 0) ctl->ticks[32 * xcd + rank] = cyc;
+    } else if (rank < kWriters + kReaders && stage >= 2) {
         const int rd = rank - kWriters;
         unsigned long long bad = 0, cyc = 0;
         for (int r = 0; r < rounds; ++r) {
             if (!wait_for<CROSS>(their_produced, static_cast<unsigned>(kWriters) * (r + 1), ctl, &team[3])) return;
             const unsigned long long t0 = wall_clock64();
             if constexpr (LD == LD_INV_PLAIN) asm volatile("buffer_inv sc1" ::: "memory");
-            for (int c0 = rd; c0 < nchunks; c0 += kReaders * 8) {
+            for (int c0 = rd; c0 < nchunks; c0 += kReaders * 8) {          // (nchunks is a multiple of kReaders * 8)
                 u4 v[8];
+                const u4* p[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p[u] = theirs + static_cast<unsigned>(c0 + kReaders * u) * 256u + tid;
+                load8<LD>(v, p);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int c = c0 + kReaders * u;
-                    if (c < nchunks) load16<LD>(v[u], theirs + static_cast<unsigned>(c) * 256u + tid);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int c = c0 + kReaders * u;
-                    if (c < nchunks) {
-                        asm volatile("" : "+v"(v[u]));
-                        const unsigned idx = static_cast<unsigned>(c) * 256u + tid;
-                        const u4 want = pattern(static_cast<unsigned>(r), idx);
-                        bad += (v[u].x != want.x) + (v[u].y != want.y) + (v[u].z != want.z) + (v[u].w != want.w);
-                    }
+                    const unsigned idx = static_cast<unsigned>(c0 + kReaders * u) * 256u + tid;
+                    const u4 want = pattern(static_cast<unsigned>(r), idx);
+                    bad += (v[u].x != want.x) + (v[u].y != want.y) + (v[u].z != want.z) + (v[u].w != want.w);
                 }
             }
             cyc += wall_clock64() - t0;
             arrive<CROSS>(their_consumed);
         }
-        if (bad) atomicAdd(&ctl->stale[0], bad);
-        if (tid == 0) atomicAdd(&ctl->cycles[0], cyc);
-    } else if (FOREIGN) {
+        // (per-thread counts meet in LDS; one word per workgroup leaves the kernel)
+        __shared__ unsigned long long wg_bad;
+        if (tid == 0) wg_bad = 0;
+        __syncthreads();
+        if (bad) atomicAdd(&wg_bad, bad);
+        __syncthreads();
+        if (tid == 0) {
+            ctl->stale[32 * xcd + rank] = wg_bad;
+            ctl->ticks[32 * xcd + rank] = cyc;
+        }
+    } else if (FOREIGN && rank < kWriters + kReaders + 8) {
         // one sweep of this XCD's 2 MB table per round, unsynchronised; 8 workgroups share it
         const u4* const tb = table + static_cast<size_t>(xcd) * ((2u << 20) / 16);
         const int fr = rank - kWriters - kReaders;
@@ -201,11 +230,12 @@ __global__ __launch_bounds__(256) void residency_kernel(u4* __restrict__ buf, si
         for (int r = 0; r < rounds; ++r) {
             for (int c0 = fr; c0 < 512; c0 += 8 * 8) {
                 u4 v[8];
+                const u4* p[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) load16<LD_PLAIN_NOINV>(v[u], tb + static_cast<unsigned>(c0 + 8 * u) * 256u + tid);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (int u = 0; u < 8; ++u) p[u] = tb + static_cast<unsigned>(c0 + 8 * u) * 256u + tid;
+                load8<LD_PLAIN_NOINV>(v, p);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { asm volatile("" : "+v"(v[u])); acc ^= v[u].x; }
+                for (int u = 0; u < 8; ++u) acc ^= v[u].x;
             }
             if (__hip_atomic_load(&ctl->abort_[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         }
@@ -215,7 +245,7 @@ __global__ __launch_bounds__(256) void residency_kernel(u4* __restrict__ buf, si
 
 struct Variant {
     const char* name;
-    void (*fn)(u4*, size_t, int, const u4*, Ctl*, unsigned*);
+    void (*fn)(u4*, size_t, int, const u4*, Ctl*, unsigned*, int);
 };
 
 #define V(st, ld, fo, cr, label) {label, residency_kernel<st, ld, fo, cr>}
@@ -234,6 +264,9 @@ static const Variant kVariants[] = {
 int main(int argc, char** argv)
 {
     const int rounds = argc > 1 ? atoi(argv[1]) : 1000;
+    const int only = argc > 2 ? atoi(argv[2]) : -1;
+    const int stage = argc > 3 ? atoi(argv[3]) : 2;             // debugging: 0 = team assembly only, 1 = + writers, 2 = everything              // run one variant only (index into kVariants)
+    setvbuf(stdout, nullptr, _IONBF, 0);                         // a GPU fault aborts the process: lose nothing
     int dev_cus = 0;
     CHECK(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, 0));
     if (dev_cus != 256) { printf("needs a 256-CU part (found %d CUs)\n", dev_cus); return 2; }
@@ -257,6 +290,8 @@ int main(int argc, char** argv)
     const size_t sizes[] = {1u << 20, 2u << 20, 3u << 20};
     for (size_t bytes : sizes) {
         for (const Variant& v : kVariants) {
+            if (only >= 0 && &v != &kVariants[only]) continue;
+            printf("%zu KB/team  %-78s ", bytes >> 10, v.name);
             Ctl h;
             float best = 1e30f;
             unsigned long long stale = 0;
@@ -266,22 +301,25 @@ int main(int argc, char** argv)
                 CHECK(hipMemset(ctl, 0, sizeof(Ctl)));
                 CHECK(hipDeviceSynchronize());
                 CHECK(hipEventRecord(a));
-                hipLaunchKernelGGL(v.fn, dim3(256), dim3(256), lds, 0, buf, bytes, rounds, table, ctl, sink);
+                hipLaunchKernelGGL(v.fn, dim3(256), dim3(256), lds, 0, buf, bytes, rounds, table, ctl, sink, stage);
                 CHECK(hipGetLastError());
                 CHECK(hipEventRecord(b));
                 CHECK(hipEventSynchronize(b));
+                CHECK(hipDeviceSynchronize());
                 float ms = 0;
                 CHECK(hipEventElapsedTime(&ms, a, b));
                 CHECK(hipMemcpy(&h, ctl, sizeof h, hipMemcpyDeviceToHost));
                 if (h.abort_[0]) aborted = true;
-                stale += h.stale[0];
+                for (int w = 0; w < 256; ++w) stale += h.stale[w];
                 if (ms < best) best = ms;
             }
             const double us_round = best * 1e3 / rounds;
-            const double rd_us = static_cast<double>(h.cycles[0]) / (8.0 * kReaders) / rounds / 100.0;   // 100 MHz counter
-            const double wr_us = static_cast<double>(h.cycles[1]) / (8.0 * kWriters) / rounds / 100.0;
-            printf("%zu KB/team  %-78s %s %8.3f us/round  (write+drain %6.2f us, read %6.2f us = %6.0f GB/s per XCD)  stale %llu\n",
-                   bytes >> 10, v.name, aborted ? "ABORTED" : "ok", us_round, wr_us, rd_us, bytes / (rd_us * 1e-6) / 1e9, stale);
+            double rd_us = 0, wr_us = 0;                                  // mean over the teams' readers / writers
+            for (int w = 0; w < 256; ++w) ((w % 32) < kWriters ? wr_us : rd_us) += static_cast<double>(h.ticks[w]);
+            rd_us = rd_us / (8.0 * kReaders) / rounds / 100.0;            // 100 MHz counter
+            wr_us = wr_us / (8.0 * kWriters) / rounds / 100.0;
+            printf("%s %8.3f us/round  (write+drain %6.2f us, read %6.2f us = %6.0f GB/s per XCD)  stale %llu\n",
+                   aborted ? "ABORTED" : "ok", us_round, wr_us, rd_us, bytes / (rd_us * 1e-6) / 1e9, stale);
         }
     }
     return 0;
