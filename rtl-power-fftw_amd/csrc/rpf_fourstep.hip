@@ -78,6 +78,16 @@ __device__ __forceinline__ void group_fft(int t, cf* x, const cf (&tw)[G::NPASS 
     phase_fetch<G, G::NPASS>(t, x, slab);
     phase_last<G>(x);
 }
+// The same with the twiddles of the passes >= 2 read from an LDS table (fill_twlds) instead of held in registers:
+// 2 (P - 1) VGPRs fewer per such pass, which the fused kernel's roles need for their per-lane constants.
+template <class G>
+__device__ __forceinline__ void group_fft_twlds(int t, cf* x, const cf (&tw)[G::NPASS - 1][G::P - 1], cf* slab, const cf* twtable)
+{
+    PhaseClock none;
+    middle_passes<G, 1, 0, true>(t, x, tw, slab, none, twtable);
+    phase_fetch<G, G::NPASS>(t, x, slab);
+    phase_last<G>(x);
+}
 
 // BLU: first step of the large Bluestein path (see bluestein_mid_kernel): the
 // frame has n_true < S::N samples, a[n] = (v[n] - 127) g[n] zero-padded to S::N
@@ -326,7 +336,8 @@ __device__ __forceinline__ unsigned l2_read(const unsigned* p)
 
 // What the two roles of a workgroup share in LDS (static: the dynamic area is full).
 struct FusedSync {
-    unsigned bar[2];          // role barriers: monotonically increasing arrival counts (8 per barrier)
+    unsigned bar[3];          // [0], [1]: role barriers, monotonically increasing arrival counts (8 per barrier);
+                              // [2]: consumer waves that have taken their columns out of the tile (8 per round)
     unsigned seen[2][2];      // [0][parity]: `consumed` as last polled by the producers' wave 0; [1][parity]: `produced`, consumers'
     unsigned abort;           // a bounded spin ran out somewhere in this workgroup (or the grid's flag was seen)
     int team[3];              // xcd, rank, ok
@@ -334,6 +345,21 @@ struct FusedSync {
 
 // Barrier among the 8 waves of one role (no s_barrier: that one spans both roles).  `target` = 8 x the number of
 // this role's barriers so far.  LDS operations of one wave execute in order, so the arrival follows its writes.
+// (split form: role_arrive where the wave is done, role_wait where it needs the others -- nothing stalls in between)
+__device__ __forceinline__ void role_arrive(FusedSync* sy, int role, int lane)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(&sy->bar[role], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ bool role_wait(FusedSync* sy, int role, unsigned target)
+{
+    unsigned spins = 0;
+    while (__hip_atomic_load(&sy->bar[role], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kLdsSpinLimit || __hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
+    }
+    return true;
+}
 __device__ __forceinline__ bool role_barrier(FusedSync* sy, int role, unsigned target, int lane)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -405,7 +431,8 @@ constexpr int fused_lds_bytes()
     constexpr int slabs = kRoleWaves * (S::SLAB_A + S::SLAB_B) * (int)sizeof(cf);
     constexpr int raw = S::N1 * (16 * S::SUBA / 2 + 1) * 4;
     constexpr int tile = S::N2 * S::ROW_PITCH * (int)sizeof(cf);
-    return slabs + tile + raw;
+    constexpr int twtables = (twlds_entries<typename S::GA>() + twlds_entries<typename S::GB>()) * (int)sizeof(cf);
+    return slabs + tile + raw + twtables;
 }
 
 template <class S, bool WINDOW, bool DMA>
@@ -435,12 +462,16 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
     cf* const slabsB = slabsA + kRoleWaves * S::SLAB_A;                                // [8][SLAB_B]
     cf* const tile = slabsB + kRoleWaves * S::SLAB_B;                                  // [N2][ROW_PITCH]
     uint8_t* const raw = reinterpret_cast<uint8_t*>(tile + N2 * S::ROW_PITCH);         // [N1][PITCH] dwords
+    cf* const twtabA = reinterpret_cast<cf*>(raw + N1 * PITCH * 4);                    // later passes' twiddles, columns
+    cf* const twtabB = twtabA + twlds_entries<GA>();                                   // ... and rows
     __shared__ FusedSync sync_;
     FusedSync* const sy = &sync_;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 
+    fill_twlds<GA, 1>(tid, kWG, tw_n1, twtabA);
+    fill_twlds<GB, 1>(tid, kWG, tw_n2, twtabB);
     // ---- team assembly -------------------------------------------------------------------------
     if (tid == 0) {
         const int xcd = static_cast<int>(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20)) & 7;   // XCC_ID[3:0]
@@ -459,7 +490,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
         sy->team[0] = xcd;
         sy->team[1] = static_cast<int>(rank);
         sy->team[2] = ok;
-        sy->bar[0] = sy->bar[1] = 0;
+        sy->bar[0] = sy->bar[1] = sy->bar[2] = 0;
         sy->seen[0][0] = sy->seen[0][1] = sy->seen[1][0] = sy->seen[1][1] = 0;
         sy->abort = 0;
     }
@@ -477,18 +508,12 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
     bool alive = true;
     FusedClock fclk;
 
-    double acc[GROUPS][P];
-#pragma unroll
-    for (int g = 0; g < GROUPS; ++g)
-#pragma unroll
-        for (int a = 0; a < P; ++a) acc[g][a] = 0.0;
-
     if (producer) {
         // ================================ producers: columns ====================================
         const int sub = lane / TA, t = lane % TA;
         cf* const slab = slabsA + rw * S::SLAB_A + sub * GA::LDS_CPX;
-        cf tw[GA::NPASS - 1][P - 1];
-        load_twiddles<GA, 1>(t, tw_n1, tw);
+        cf tw[GA::NPASS - 1][P - 1];                      // (pass 1 only: the later passes' come from twtabA)
+        load_twiddles<GA, 1, true>(t, tw_n1, tw);
         // this lane's columns never change: inter-step twiddles (and window) once, into registers
         cf wstep[GROUPS][P];
         float wsgn[WINDOW ? GROUPS : 1][P];
@@ -522,15 +547,31 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
         };
         if (nj > 0 && xcd * FR + fsl < nframes) stage_rows(xcd * FR + fsl);
         unsigned nbar = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane);          // the first round's raw rows are in
         fclk.start();
 #pragma unroll 1
         for (int j = 0; j < nj && alive; ++j) {
             const int f = (xcd + 8 * j) * FR + fsl;
             const bool valid = f < nframes;
-            // this round's raw rows (staged a round ahead) have landed, for every producer wave
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // Both column groups' samples go to registers first: the raw area is then free for the next round's rows,
+            // whose LDS-DMA runs under this round's arithmetic.
+            uint32_t iq[GROUPS][P / 2];          // two samples per register: I0 Q0 I1 Q1
+            if (valid) {
+#pragma unroll
+                for (int g = 0; g < GROUPS; ++g) {
+                    const int cl = (rw * GROUPS + g) * S::SUBA + sub;
+#pragma unroll
+                    for (int a = 0; a < P; a += 2) {
+                        const uint32_t lo = *reinterpret_cast<const uint16_t*>(raw + 4 * ((t + TA * a) * PITCH + (cl >> 1)) + 2 * (cl & 1));
+                        const uint32_t hi = *reinterpret_cast<const uint16_t*>(raw + 4 * ((t + TA * (a + 1)) * PITCH + (cl >> 1)) + 2 * (cl & 1));
+                        iq[g][a / 2] = lo | (hi << 16);
+                    }
+                }
+            }
             if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;
-            FSTAMP(0);                       // raw rows staged
+            if (j + 1 < nj && f + 8 * FR < nframes) stage_rows(f + 8 * FR);
+            FSTAMP(0);                       // samples in registers, next rows on their way
             cf* const Yf = Yteam + static_cast<size_t>(j & 1) * FR * N;
 #pragma unroll
             for (int g = 0; g < GROUPS; ++g) {
@@ -542,25 +583,30 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                     cf x[P];
 #pragma unroll
                     for (int a = 0; a < P; ++a) {
-                        const int n1 = t + TA * a;
-                        const uint32_t iq =
-                            *reinterpret_cast<const uint16_t*>(raw + 4 * (n1 * PITCH + (cl >> 1)) + 2 * (cl & 1));
-                        const cf v = iq_plus_2p23(iq);
+                        const cf v = (a & 1) ? iq_pair_plus_2p23<1>(iq[g][a / 2]) : iq_pair_plus_2p23<0>(iq[g][a / 2]);
                         if constexpr (WINDOW) x[a] = (v - (kTwo23 + 127.0f)) * wsgn[g][a];
                         else x[a] = v * sgn + off;
                     }
-                    group_fft<GA>(t, x, tw, slab);
+                    group_fft_twlds<GA>(t, x, tw, slab, twtabA);
                     exchange_sync<false>();
 #pragma unroll
                     for (int a = 0; a < P; ++a) slab[GA::slot(bin_of<GA>(t, a))] = cmul(x[a], wstep[g][a]);
                     exchange_sync<false>();
                 }
-                // the buffer held round j - 2: the team has finished reading it (trivially true in rounds 0, 1)
                 if (g == 0) {
                     FSTAMP(1);                   // first column group transformed
+                    // The one vmcnt(0) of a round sits HERE: the previous round's stores have had a whole transform to
+                    // drain (write-through: ~3 us behind the issue under load) and the next raw rows are in or nearly
+                    // so.  Once every producer wave is past it the workgroup counts itself in for round j - 1.
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;
+                    if (j >= 1 && rw == 0 && lane == 0)
+                        __hip_atomic_fetch_add(&ctl->produced[xcd][(j - 1) & 1][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    FSTAMP(2);                   // drained, arrived
+                    // the buffer held round j - 2: the team has finished reading it (trivially true in rounds 0, 1)
                     if (j >= 2 && !(alive = team_wait(ctl, sy, &ctl->consumed[xcd][j & 1][0], &sy->seen[0][j & 1], 32u * (j / 2),
                                                       rw == 0, lane))) break;
-                    FSTAMP(2);                   // wait: buffer free
+                    FSTAMP(3);                   // wait: buffer free
                 }
                 if (valid) {
                     cf* const ycol = Yf + static_cast<size_t>(c) * RT;      // tile-major, like K2a
@@ -576,26 +622,27 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                 }
             }
             if (!alive) break;
-            FSTAMP(3);                       // second group transformed, Y stores issued
-            // every producer wave is done with the raw rows: stage the next round's behind the stores
-            if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;
-            if (j + 1 < nj && f + 8 * FR < nframes) stage_rows(f + 8 * FR);
-            // the round's rows of Y are in the L2 once this wave's stores have drained; the last wave to get
-            // there counts the workgroup in (the next round's top-of-loop barrier would do, but a round late)
+            FSTAMP(4);                       // second group transformed, Y stores issued
+        }
+        // the last round's stores
+        if (alive && nj > 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            FSTAMP(4);                       // stores drained (+ next raw rows landed)
-            if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;
-            if (rw == 0 && lane == 0)
-                __hip_atomic_fetch_add(&ctl->produced[xcd][j & 1][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            FSTAMP(5);
+            if ((alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane)) && rw == 0 && lane == 0)
+                __hip_atomic_fetch_add(&ctl->produced[xcd][(nj - 1) & 1][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         fclk.publish(0, rw == 0 && lane == 0);
     } else {
         // ================================ consumers: rows =======================================
         const int sub = lane / TB, t = lane % TB;
         cf* const slab = slabsB + rw * S::SLAB_B + sub * GB::LDS_CPX;
-        cf tw[GB::NPASS - 1][P - 1];
-        load_twiddles<GB, 1>(t, tw_n2, tw);
+        cf tw[GB::NPASS - 1][P - 1];                      // (pass 1 only: the later passes' come from twtabB)
+        load_twiddles<GB, 1, true>(t, tw_n2, tw);
+        // (the accumulators belong to this branch alone: declared outside they would cost the producers 32 registers)
+        double acc[GROUPS][P];
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g)
+#pragma unroll
+            for (int a = 0; a < P; ++a) acc[g][a] = 0.0;
         constexpr int PERB = N2 * RT / kRoleThreads / 2;     // 16-byte loads per thread and tile
         typedef float f4 __attribute__((ext_vector_type(4)));
         unsigned nbar = 0;
@@ -629,6 +676,8 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                              : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
                              : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(src[5]), "v"(src[6]), "v"(src[7])
                              : "memory");
+                // the previous round's columns have left the tile (arrivals posted long ago: see below)
+                if (!(alive = role_wait(sy, 2, static_cast<unsigned>(kRoleWaves) * j))) break;
 #pragma unroll
                 for (int i = 0; i < PERB; ++i) {
                     const int idx = i * kRoleThreads + rtid;
@@ -650,33 +699,37 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                     cf x[P];
 #pragma unroll
                     for (int a = 0; a < P; ++a) x[a] = tile[(t + TB * a) * S::ROW_PITCH + jrow];
-                    group_fft<GB>(t, x, tw, slab);
+                    // second group's column read: this wave is done with the tile.  Arrive now, nobody waits here; the
+                    // next round's tile write waits for all eight arrivals, by then long posted -- a barrier behind the
+                    // transforms, where the waves are skewed, cost 1.5 us per round
+                    if (g == GROUPS - 1) role_arrive(sy, 2, lane);
+                    group_fft_twlds<GB>(t, x, tw, slab, twtabB);
                     phase_accumulate(x, acc[g], P);
                     exchange_sync<false>();
                 }
+            } else {
+                role_arrive(sy, 2, lane);
             }
             FSTAMP(3);                       // rows transformed
-            // the tile is rewritten next round: every consumer wave has read its columns
-            if (!(alive = role_barrier(sy, 1, (nbar += kRoleWaves), lane))) break;
-            FSTAMP(4);
         }
         fclk.publish(8, rw == 0 && lane == 0);
-    }
-
-    // ---- partial spectrum of (team, frame slot): rows of tile tl ---------------------------------------
-    __syncthreads();                                 // (waves that gave up have left: the barrier does not wait for them)
-    if (__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
-    double* const stage = reinterpret_cast<double*>(tile);                            // [N2 k2][ROW_PITCH]
-    if (!producer) {
-        const int sub = lane / TB, t = lane % TB;
+        // partial spectrum of (team, frame slot): the accumulators go through the tile area (the consumers' own: every
+        // consumer wave has left its last round's column reads behind at that round's barrier) as [N2 k2][ROW_PITCH] doubles
+        if (alive) {
+            double* const stage = reinterpret_cast<double*>(tile);
 #pragma unroll
-        for (int g = 0; g < GROUPS; ++g) {
-            const int jrow = (rw * GROUPS + g) * S::SUBB + sub;
+            for (int g = 0; g < GROUPS; ++g) {
+                const int jrow = (rw * GROUPS + g) * S::SUBB + sub;
 #pragma unroll
-            for (int a = 0; a < P; ++a) stage[bin_of<GB>(t, a) * S::ROW_PITCH + jrow] = acc[g][a];
+                for (int a = 0; a < P; ++a) stage[bin_of<GB>(t, a) * S::ROW_PITCH + jrow] = acc[g][a];
+            }
         }
     }
-    __syncthreads();
+
+    // ---- partial spectrum of (team, frame slot): rows of tile tl, streamed out by all sixteen waves ----------------
+    __syncthreads();                                 // (waves that gave up have left: the barrier does not wait for them)
+    if (__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
+    const double* const stage = reinterpret_cast<const double*>(tile);                // [N2 k2][ROW_PITCH]
     double* const out = partial + (static_cast<size_t>(xcd) * FR + fsl) * N + RT * tl;
 #pragma unroll
     for (int i = 0; i < N2 * RT / kWG; ++i) {

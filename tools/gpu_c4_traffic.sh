@@ -6,12 +6,12 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/c4traffic
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $GRAFT_REPO_ROOT/tools/gpu_fused_profile.py 262144 512"
-for c in FETCH_SIZE WRITE_SIZE; do
+for c in FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o c4 -- $CMD > $OUT/$c.log 2>&1
 done
 python3 - <<PY
 import csv, collections, glob
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
+for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"):
     files = glob.glob("$OUT/%s/**/c4_counter_collection.csv" % c, recursive=True)
     acc = collections.defaultdict(list)
     for f in files:

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 120 rocgdb -batch -ex "set pagination off" -ex "set amdgpu precise-memory on" -ex run -ex "x/3i \$pc-8" -ex "info registers s0 s1 s2 s3 s6 s7 s8 s9 s12 s13 s18 s19 s20 s21 s26 s27 s33 s36 s42" -ex "p/x \$v2" -ex "p/x \$v3"  -ex "p/x \$v92" -ex "p/x \$v93" -ex "p/x \$v90" -ex "p/x \$v91" -ex "x/30i \$pc-100" --args tools/l2_residency_bench 10 1 2 2>&1 | grep -v "^\[New\|^\[Thread\|warning" | head -100 | cut -c1-330
+timeout 120 rocgdb -batch -ex "set pagination off" -ex "set amdgpu precise-memory on" -ex run -ex "x/4i \$pc-16" -ex "info registers s0 s1 s2 s3 s4 s5 s6 s7 s8 s9 s10 s11" --args tools/l2_residency_bench 10 6 2 2>&1 | grep -v "^\[New\|^\[Thread\|warning" | head -40 | cut -c1-250

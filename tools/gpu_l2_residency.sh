@@ -13,7 +13,7 @@ rc=$?
 cat $OUT/timing.txt
 if [ $rc -ne 0 ]; then
   echo "timing run failed (rc=$rc): variants one by one, 100 rounds"
-  for v in 0 1 2 3 4 5 6 7 8; do timeout 30 $BIN 100 $v 2>&1 | grep -v "^#" | cut -c1-200; done
+  for v in 0 1 2 3 4 5 6 7 8 9; do timeout 30 $BIN 100 $v 2>&1 | grep -v "^#" | cut -c1-200; done
   exit 1
 fi
 for c in FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum; do
@@ -25,9 +25,9 @@ rows = collections.OrderedDict()
 for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"):
     for f in glob.glob("$OUT/%s/**/l2_counter_collection.csv" % c, recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != c or "residency_kernel" not in r["Kernel_Name"]:
+            if r["Counter_Name"] != c or not ("residency_kernel" in r["Kernel_Name"] or "team32_kernel" in r["Kernel_Name"]):
                 continue
-            m = re.search(r"residency_kernel<([^>]*)>", r["Kernel_Name"])
+            m = re.search(r"((?:residency|team32)_kernel<[^>]*>)", r["Kernel_Name"])
             rows.setdefault(m.group(1), collections.defaultdict(list))[c].append(float(r["Counter_Value"]))
 print("# per launch, in launch order (2 launches per size: 1, 2, 3 MB per team); FETCH/WRITE_SIZE in KiB as reported")
 print("# template args = <store kind, load kind, foreign, cross>: store 0 plain 1 nt 2 sc1 3 sc0sc1; load 0 inv+plain 1 sc1 2 plain-noinv 3 sc0sc1")

@@ -243,12 +243,91 @@ __global__ __launch_bounds__(256) void residency_kernel(u4* __restrict__ buf, si
     }
 }
 
+
+// All 32 workgroups of a team write their share of the buffer, then read a NEIGHBOUR's share (what the fused four-step
+// kernel's producers and consumers do with Y at full width): how long do the store drain and the read-back of
+// bytes / 32 per CU take when every CU of the XCD is at it?  The same kernel signature as above (table, sink unused).
+template <int ST, int LD>
+__global__ __launch_bounds__(256) void team32_kernel(u4* __restrict__ buf, size_t bytes, int rounds, const u4* __restrict__,
+                                                     Ctl* __restrict__ ctl, unsigned*, int stage)
+{
+    extern __shared__ unsigned char smem[];
+    __shared__ int team[4];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        const int xcd = static_cast<int>(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20)) & 7;
+        const unsigned rank = __hip_atomic_fetch_add(&ctl->members[xcd][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&ctl->registered[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(&ctl->registered[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > kSpinLimit) { ok = 0; break; }
+        }
+        for (int x = 0; ok && x < 8; ++x)
+            if (__hip_atomic_load(&ctl->members[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 32u) ok = 0;
+        if (!ok) __hip_atomic_store(&ctl->abort_[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        team[0] = xcd;
+        team[1] = static_cast<int>(rank);
+        team[2] = ok;
+        smem[0] = 0;
+    }
+    __syncthreads();
+    const int xcd = team[0], rank = team[1];
+    if (!team[2] || stage == 0) return;
+    u4* const mine = buf + ((16u << 20) / 16) * static_cast<size_t>(xcd);
+    unsigned* const produced = &ctl->produced[xcd][0];
+    unsigned* const consumed = &ctl->consumed[xcd][0];
+    const int nchunks = static_cast<int>(bytes / 4096);            // a multiple of 32 x 8
+    const int src = (rank + 1) & 31;                               // whose chunks this workgroup reads
+    unsigned long long bad = 0, wr = 0, rd = 0;
+    for (int r = 0; r < rounds; ++r) {
+        if (r > 0 && !wait_for<false>(consumed, 32u * r, ctl, &team[3])) return;
+        unsigned long long t0 = wall_clock64();
+        for (int c = rank; c < nchunks; c += 32) {
+            const unsigned idx = static_cast<unsigned>(c) * 256u + tid;
+            store16<ST>(mine + idx, pattern(static_cast<unsigned>(r), idx));
+        }
+        arrive<false>(produced);
+        wr += wall_clock64() - t0;
+        if (!wait_for<false>(produced, 32u * (r + 1), ctl, &team[3])) return;
+        t0 = wall_clock64();
+        if constexpr (LD == LD_INV_PLAIN) asm volatile("buffer_inv sc1" ::: "memory");
+        for (int c0 = src; c0 < nchunks; c0 += 32 * 8) {
+            u4 v[8];
+            const u4* p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = mine + static_cast<unsigned>(c0 + 32 * u) * 256u + tid;
+            load8<LD>(v, p);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned idx = static_cast<unsigned>(c0 + 32 * u) * 256u + tid;
+                const u4 want = pattern(static_cast<unsigned>(r), idx);
+                bad += (v[u].x != want.x) + (v[u].y != want.y) + (v[u].z != want.z) + (v[u].w != want.w);
+            }
+        }
+        rd += wall_clock64() - t0;
+        arrive<false>(consumed);
+    }
+    __shared__ unsigned long long wg_bad;
+    if (tid == 0) wg_bad = 0;
+    __syncthreads();
+    if (bad) atomicAdd(&wg_bad, bad);
+    __syncthreads();
+    if (tid == 0) {
+        ctl->stale[32 * xcd + rank] = wg_bad;
+        ctl->ticks[32 * xcd + rank] = (wr << 32) | (rd & 0xffffffffull);   // both fit 32 bits (100 MHz ticks)
+    }
+}
+
 struct Variant {
+    bool team32;       // all 32 workgroups of a team write, then read a neighbour's share
     const char* name;
     void (*fn)(u4*, size_t, int, const u4*, Ctl*, unsigned*, int);
 };
 
-#define V(st, ld, fo, cr, label) {label, residency_kernel<st, ld, fo, cr>}
+#define V(st, ld, fo, cr, label) {false, label, residency_kernel<st, ld, fo, cr>}
+#define V32(st, ld, label) {true, label, team32_kernel<st, ld>}
 static const Variant kVariants[] = {
     V(ST_PLAIN, LD_INV_PLAIN, false, false, "plain stores, buffer_inv sc1 + plain loads"),
     V(ST_PLAIN, LD_SC1, false, false, "plain stores, sc1 loads"),
@@ -256,9 +335,13 @@ static const Variant kVariants[] = {
     V(ST_NT, LD_INV_PLAIN, false, false, "nt stores, buffer_inv sc1 + plain loads"),
     V(ST_SC1, LD_SC1, false, false, "sc1 stores, sc1 loads"),
     V(ST_SC0SC1, LD_SC0SC1, false, false, "sc0 sc1 stores, sc0 sc1 loads"),
-    V(ST_PLAIN, LD_INV_PLAIN, true, false, "plain stores, buffer_inv sc1 + plain loads, FOREIGN 2 MB stream"),
-    V(ST_PLAIN, LD_SC1, true, false, "plain stores, sc1 loads, FOREIGN 2 MB stream"),
+    // (the FOREIGN rows -- a third group of workgroups streaming a 2 MB table through the same L2, what the W_N table did
+    //  to the round-2 fused kernel -- fault in their sweep on this stack and are left out: the round-4 fused kernel keeps
+    //  its step twiddles in registers and has no such stream)
     V(ST_SC1, LD_SC1, false, true, "CROSS-XCD calibration: sc1 stores, sc1 loads of the NEXT XCD's buffer"),
+    V32(ST_PLAIN, LD_SC1, "ALL 32 CUs write, then read a neighbour's share: plain stores, sc1 loads"),
+    V32(ST_PLAIN, LD_INV_PLAIN, "ALL 32 CUs write, then read a neighbour's share: plain stores, buffer_inv sc1 + plain loads"),
+    V32(ST_SC1, LD_SC1, "ALL 32 CUs write, then read a neighbour's share: sc1 stores, sc1 loads (write-through)"),
 };
 
 int main(int argc, char** argv)
@@ -315,9 +398,15 @@ int main(int argc, char** argv)
             }
             const double us_round = best * 1e3 / rounds;
             double rd_us = 0, wr_us = 0;                                  // mean over the teams' readers / writers
-            for (int w = 0; w < 256; ++w) ((w % 32) < kWriters ? wr_us : rd_us) += static_cast<double>(h.ticks[w]);
-            rd_us = rd_us / (8.0 * kReaders) / rounds / 100.0;            // 100 MHz counter
-            wr_us = wr_us / (8.0 * kWriters) / rounds / 100.0;
+            if (v.team32) {
+                for (int w = 0; w < 256; ++w) { wr_us += static_cast<double>(h.ticks[w] >> 32); rd_us += static_cast<double>(h.ticks[w] & 0xffffffffull); }
+                rd_us = rd_us / 256.0 / rounds / 100.0;
+                wr_us = wr_us / 256.0 / rounds / 100.0;
+            } else {
+                for (int w = 0; w < 256; ++w) ((w % 32) < kWriters ? wr_us : rd_us) += static_cast<double>(h.ticks[w]);
+                rd_us = rd_us / (8.0 * kReaders) / rounds / 100.0;            // 100 MHz counter
+                wr_us = wr_us / (8.0 * kWriters) / rounds / 100.0;
+            }
             printf("%s %8.3f us/round  (write+drain %6.2f us, read %6.2f us = %6.0f GB/s per XCD)  stale %llu\n",
                    aborted ? "ABORTED" : "ok", us_round, wr_us, rd_us, bytes / (rd_us * 1e-6) / 1e9, stale);
         }
