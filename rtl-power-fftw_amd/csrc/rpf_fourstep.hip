@@ -306,11 +306,11 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_rows_kernel(const cf* __restr
 // at creation and otherwise keeps K2a/K2b.
 struct FusedCtl {
     unsigned arrivals[8][32];     // [xcd][0]: members registered (own 128-byte line each)
-    // One counter per buffer (round parity): a cumulative count over all rounds would let a workgroup that is a round
-    // ahead stand in for one that is a round behind (31 arrivals of round j + 1 of round j + 1 = 32).  Two rounds
-    // ahead is impossible: writing buffer p again needs all 32 consumers of its previous round.
-    unsigned produced[8][2][32];  // [xcd][parity][0]: producer arrivals, 32 per round of that parity
-    unsigned consumed[8][2][32];  // [xcd][parity][0]: consumer arrivals
+    // Cumulative counts are safe with ONE buffer per team: a producer arrives for round j only after all 32 consumers of
+    // round j - 1, a consumer for round j only after all 32 producers of round j -- no arrival of a later round can
+    // stand in for a missing one of an earlier round.  (With two buffers it can: 31 of round j + 1 of round j + 1.)
+    unsigned produced[8][32];     // [xcd][0]: producer arrivals, 32 per round
+    unsigned consumed[8][32];     // [xcd][0]: consumer arrivals, 32 per round
     unsigned registered[32];      // [0]: workgroups registered, grid-wide
     unsigned abort[32];           // [0]: != 0 -> results invalid
 };
@@ -338,7 +338,7 @@ __device__ __forceinline__ unsigned l2_read(const unsigned* p)
 struct FusedSync {
     unsigned bar[3];          // [0], [1]: role barriers, monotonically increasing arrival counts (8 per barrier);
                               // [2]: consumer waves that have taken their columns out of the tile (8 per round)
-    unsigned seen[2][2];      // [0][parity]: `consumed` as last polled by the producers' wave 0; [1][parity]: `produced`, consumers'
+    unsigned seen[2];         // [0]: `consumed` as last polled by the producers' wave 0; [1]: `produced`, consumers'
     unsigned abort;           // a bounded spin ran out somewhere in this workgroup (or the grid's flag was seen)
     int team[3];              // xcd, rank, ok
 };
@@ -386,7 +386,7 @@ __device__ __forceinline__ bool team_wait(FusedCtl* ctl, FusedSync* sy, const un
                 if (lane == 0) __hip_atomic_store(seen, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 return true;
             }
-            __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_s_sleep(2);
             if (++spins > kSpinLimit || __hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ||
                 ((spins & 255u) == 0 && ctl_load(&ctl->abort[0]) != 0)) {
                 if (lane == 0) {
@@ -432,7 +432,8 @@ constexpr int fused_lds_bytes()
     constexpr int raw = S::N1 * (16 * S::SUBA / 2 + 1) * 4;
     constexpr int tile = S::N2 * S::ROW_PITCH * (int)sizeof(cf);
     constexpr int twtables = (twlds_entries<typename S::GA>() + twlds_entries<typename S::GB>()) * (int)sizeof(cf);
-    return slabs + tile + raw + twtables;
+    constexpr int steptab = 16 * S::SUBA * 8 * (int)sizeof(cf);        // the register-index factor of W_N^{n2 k1}, per column
+    return slabs + tile + raw + twtables + steptab;
 }
 
 template <class S, bool WINDOW, bool DMA>
@@ -464,6 +465,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
     uint8_t* const raw = reinterpret_cast<uint8_t*>(tile + N2 * S::ROW_PITCH);         // [N1][PITCH] dwords
     cf* const twtabA = reinterpret_cast<cf*>(raw + N1 * PITCH * 4);                    // later passes' twiddles, columns
     cf* const twtabB = twtabA + twlds_entries<GA>();                                   // ... and rows
+    cf* const steptab = twtabB + twlds_entries<GB>();                                  // [COLS][P]: W_N^{n2 (bin_of(0, a))}
     __shared__ FusedSync sync_;
     FusedSync* const sy = &sync_;
 
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
         sy->team[1] = static_cast<int>(rank);
         sy->team[2] = ok;
         sy->bar[0] = sy->bar[1] = sy->bar[2] = 0;
-        sy->seen[0][0] = sy->seen[0][1] = sy->seen[1][0] = sy->seen[1][1] = 0;
+        sy->seen[0] = sy->seen[1] = 0;
         sy->abort = 0;
     }
     __syncthreads();                                 // the only workgroup-wide barrier before the output stage
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
     const int fsl = rank / TPF, tl = rank % TPF;            // frame slot of the round, tile of the frame
     const int nrounds = (nframes + FR - 1) / FR;
     const int nj = xcd < nrounds ? (nrounds - xcd + 7) / 8 : 0;    // this team's rounds: xcd, xcd + 8, ...
-    cf* const Yteam = Yall + static_cast<size_t>(xcd) * 2 * FR * N + static_cast<size_t>(fsl) * N;   // + (j & 1) * FR * N
+    cf* const Yteam = Yall + static_cast<size_t>(xcd) * FR * N + static_cast<size_t>(fsl) * N;
 
     const bool producer = wave < kRoleWaves;
     const int rw = wave & (kRoleWaves - 1);          // wave inside its role
@@ -510,22 +512,27 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
 
     if (producer) {
         // ================================ producers: columns ====================================
-        const int sub = lane / TA, t = lane % TA;
-        cf* const slab = slabsA + rw * S::SLAB_A + sub * GA::LDS_CPX;
+        const int sub0 = lane / TA, t0 = lane % TA;
         cf tw[GA::NPASS - 1][P - 1];                      // (pass 1 only: the later passes' come from twtabA)
-        load_twiddles<GA, 1, true>(t, tw_n1, tw);
-        // this lane's columns never change: inter-step twiddles (and window) once, into registers
-        cf wstep[GROUPS][P];
+        load_twiddles<GA, 1, true>(t0, tw_n1, tw);
+        // This lane's columns never change.  The inter-step twiddle of (column c, register a) is W_N^{c bin_of(t, a)} and
+        // bin_of(t, a) = bin_of(t, 0) + bin_of(0, a) for these geometries (the digits of 8 t + a do not carry): one
+        // per-lane factor per column in a register, the eight per-register factors of the column in LDS -- 4 VGPRs
+        // instead of 32 at the price of a second complex product per value.  (twN is in lane order: twN[c N1 + T a + t].)
+        cf ustep[GROUPS];
         float wsgn[WINDOW ? GROUPS : 1][P];
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
-            const int c = COLS * tl + (rw * GROUPS + g) * S::SUBA + sub;
+            const int cl = (rw * GROUPS + g) * S::SUBA + sub0;
+            const int c = COLS * tl + cl;
+            ustep[g] = twN[static_cast<size_t>(c) * N1 + t0];
+            if (t0 < P) steptab[cl * P + t0] = twN[static_cast<size_t>(c) * N1 + TA * t0];
+            static_assert(TA >= P, "one lane per register index");
 #pragma unroll
-            for (int a = 0; a < P; ++a) {
-                wstep[g][a] = twN[static_cast<size_t>(c) * N1 + TA * a + t];
-                if constexpr (WINDOW) wsgn[g][a] = window[static_cast<size_t>(c) * N1 + t + TA * a] * ((c & 1) ? -1.0f : 1.0f);
-            }
+            for (int a = 0; a < P; ++a)
+                if constexpr (WINDOW) wsgn[g][a] = window[static_cast<size_t>(c) * N1 + t0 + TA * a] * ((c & 1) ? -1.0f : 1.0f);
         }
+        exchange_sync<false>();              // (steptab rows are written and read by the same lane group)
         // raw rows of (frame f, tile tl) -> LDS, asynchronously (LDS-DMA) when DMA
         auto stage_rows = [&](int f) {
             const uint8_t* const frame = stream + static_cast<size_t>(f) * (2 * N);
@@ -554,6 +561,13 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
         for (int j = 0; j < nj && alive; ++j) {
             const int f = (xcd + 8 * j) * FR + fsl;
             const bool valid = f < nframes;
+            // Per-lane indices are re-derived every round from an opaque copy of the lane number: hoisted out of the loop
+            // they -- and every LDS offset and store address built from them, all loop-invariant now that the team has
+            // ONE buffer -- stay live across the round and spill at 128 VGPRs.
+            int lane_ = lane;
+            asm volatile("" : "+v"(lane_));
+            const int sub = lane_ / TA, t = lane_ % TA;
+            cf* const slab = slabsA + rw * S::SLAB_A + sub * GA::LDS_CPX;
             // Both column groups' samples go to registers first: the raw area is then free for the next round's rows,
             // whose LDS-DMA runs under this round's arithmetic.
             uint32_t iq[GROUPS][P / 2];          // two samples per register: I0 Q0 I1 Q1
@@ -572,7 +586,10 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
             if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;
             if (j + 1 < nj && f + 8 * FR < nframes) stage_rows(f + 8 * FR);
             FSTAMP(0);                       // samples in registers, next rows on their way
-            cf* const Yf = Yteam + static_cast<size_t>(j & 1) * FR * N;
+            // Both column groups are transformed BEFORE the team's one buffer is free (the consumers are still loading
+            // the previous round out of it): the second group waits in this wave's slab in natural k1 order, the
+            // first in registers.
+            cf y0[P];
 #pragma unroll
             for (int g = 0; g < GROUPS; ++g) {
                 const int cl = (rw * GROUPS + g) * S::SUBA + sub;       // this lane group's column inside the tile
@@ -589,27 +606,31 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                     }
                     group_fft_twlds<GA>(t, x, tw, slab, twtabA);
                     exchange_sync<false>();
+                    if (g == 0) {
 #pragma unroll
-                    for (int a = 0; a < P; ++a) slab[GA::slot(bin_of<GA>(t, a))] = cmul(x[a], wstep[g][a]);
-                    exchange_sync<false>();
+                        for (int a = 0; a < P; ++a) y0[a] = cmul(cmul(x[a], ustep[0]), steptab[cl * P + a]);
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < P; ++a)
+                            slab[GA::slot(bin_of<GA>(t, a))] = cmul(cmul(x[a], ustep[g]), steptab[cl * P + a]);
+                        exchange_sync<false>();
+                    }
                 }
-                if (g == 0) {
-                    FSTAMP(1);                   // first column group transformed
-                    // The one vmcnt(0) of a round sits HERE: the previous round's stores have had a whole transform to
-                    // drain (write-through: ~3 us behind the issue under load) and the next raw rows are in or nearly
-                    // so.  Once every producer wave is past it the workgroup counts itself in for round j - 1.
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;
-                    if (j >= 1 && rw == 0 && lane == 0)
-                        __hip_atomic_fetch_add(&ctl->produced[xcd][(j - 1) & 1][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    FSTAMP(2);                   // drained, arrived
-                    // the buffer held round j - 2: the team has finished reading it (trivially true in rounds 0, 1)
-                    if (j >= 2 && !(alive = team_wait(ctl, sy, &ctl->consumed[xcd][j & 1][0], &sy->seen[0][j & 1], 32u * (j / 2),
-                                                      rw == 0, lane))) break;
-                    FSTAMP(3);                   // wait: buffer free
-                }
-                if (valid) {
-                    cf* const ycol = Yf + static_cast<size_t>(c) * RT;      // tile-major, like K2a
+            }
+            FSTAMP(1);                       // both column groups transformed
+            // the team has finished reading the previous round out of the buffer
+            if (j >= 1 && !(alive = team_wait(ctl, sy, &ctl->consumed[xcd][0], &sy->seen[0], 32u * j, rw == 0, lane))) break;
+            FSTAMP(2);                       // wait: buffer free
+            if (valid) {
+#pragma unroll
+                for (int g = GROUPS - 1; g >= 0; --g) {
+                    const int c = COLS * tl + (rw * GROUPS + g) * S::SUBA + sub;
+                    if (g == 0) {
+#pragma unroll
+                        for (int a = 0; a < P; ++a) slab[GA::slot(bin_of<GA>(t, a))] = y0[a];
+                        exchange_sync<false>();
+                    }
+                    cf* const ycol = Yteam + static_cast<size_t>(c) * RT;      // tile-major, like K2a
 #pragma unroll
                     for (int a = 0; a < P / 2; ++a) {
                         const int e = 2 * t + 2 * TA * a;
@@ -621,14 +642,14 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                     exchange_sync<false>();
                 }
             }
-            if (!alive) break;
-            FSTAMP(4);                       // second group transformed, Y stores issued
-        }
-        // the last round's stores
-        if (alive && nj > 0) {
+            // The round's rows of Y sit in the team's L2 once every producer wave's stores have drained (plain stores:
+            // the lines stay there, dirty -- profiles/r04_l2_residency.txt); the next round's raw rows landed long ago.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if ((alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane)) && rw == 0 && lane == 0)
-                __hip_atomic_fetch_add(&ctl->produced[xcd][(nj - 1) & 1][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            FSTAMP(3);                       // stores issued and drained
+            if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;
+            if (rw == 0 && lane == 0)
+                __hip_atomic_fetch_add(&ctl->produced[xcd][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            FSTAMP(4);                       // arrived
         }
         fclk.publish(0, rw == 0 && lane == 0);
     } else {
@@ -651,10 +672,10 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
         for (int j = 0; j < nj && alive; ++j) {
             const int f = (xcd + 8 * j) * FR + fsl;
             const bool valid = f < nframes;
-            if (!(alive = team_wait(ctl, sy, &ctl->produced[xcd][j & 1][0], &sy->seen[1][j & 1], 32u * (j / 2 + 1), rw == 0, lane))) break;
+            if (!(alive = team_wait(ctl, sy, &ctl->produced[xcd][0], &sy->seen[1], 32u * (j + 1), rw == 0, lane))) break;
             FSTAMP(0);                       // wait: round produced
             if (valid) {
-                const cf* const yt = Yteam + static_cast<size_t>(j & 1) * FR * N + static_cast<size_t>(tl) * (N2 * RT);
+                const cf* const yt = Yteam + static_cast<size_t>(tl) * (N2 * RT);
                 // sc1 loads: served by the L2, never by this CU's L1 (other CUs wrote these lines); 16 bytes per lane,
                 // all eight of a thread's loads in flight -- and the wait for them in the SAME asm statement: the
                 // compiler does not know that an asm load's destination is written when the data returns, and is free
@@ -688,9 +709,9 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
             }
             FSTAMP(1);                       // tile loaded
             if (!(alive = role_barrier(sy, 1, (nbar += kRoleWaves), lane))) break;
-            // every consumer wave's loads have returned: the team may overwrite this buffer (round j + 2)
+            // every consumer wave's loads have returned: the team may overwrite the buffer
             if (rw == 0 && lane == 0)
-                __hip_atomic_fetch_add(&ctl->consumed[xcd][j & 1][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&ctl->consumed[xcd][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             FSTAMP(2);
             if (valid) {
 #pragma unroll
@@ -1048,10 +1069,10 @@ hipError_t launch_fourstep(int N, bool window, bool use_dma, const uint8_t* d_st
 }
 
 // ---- fused four-step -----------------------------------------------------------
-size_t fourstep_fused_scratch_bytes(int N)       // Y of two rounds per XCD: 8 x 2 x 2 MB
+size_t fourstep_fused_scratch_bytes(int N)       // Y of one round per XCD: 8 x 2 MB
 {
     const SplitInfo* s = find_split(N);
-    return s ? sizeof(cf) * static_cast<size_t>(s->N) * s->fused_fr * 8 * 2 : 0;
+    return s ? sizeof(cf) * static_cast<size_t>(s->N) * s->fused_fr * 8 : 0;
 }
 int fourstep_fused_slots(int N)
 {

@@ -271,9 +271,11 @@ def test_four_step_sizes_match_oracle(N, torch_dev):
 @pytest.mark.parametrize("N", [16384, 32768, 65536, 131072, 262144])
 def test_fused_four_step_equals_the_two_kernel_path(N, torch_dev):
     """The fused persistent kernel (intermediate kept in the XCDs' L2, teams synchronised through
-    per-XCD counters) against the two-kernel path (intermediate through HBM): same arithmetic per
-    frame, only the grouping of the f64 partial sums differs.  Frame counts that leave teams and
-    frame slots idle, several launches back to back on one engine (stale L2 lines, counters)."""
+    per-XCD counters) against the two-kernel path (intermediate through HBM): the same transforms per
+    frame; the inter-step twiddle is the product of two table values in the fused kernel (one more
+    float32 rounding per value, ~6e-8 relative) and the f64 partial sums are grouped differently.
+    Frame counts that leave teams and frame slots idle, several launches back to back on one engine
+    (stale L2 lines, counters)."""
     import torch
     R = 5 * (262144 // N) * 8 + 5                    # a few full rounds and a ragged tail
     stream = rpf.synth.uniform_iq(17 + N % 31, N * R)
@@ -293,7 +295,7 @@ def test_fused_four_step_equals_the_two_kernel_path(N, torch_dev):
                     torch.cuda.synchronize()
                     outs.append(d_out.cpu().numpy())
                 assert np.all(np.isfinite(outs[0]))
-                assert max_rel(outs[0], outs[1]) < 1e-12, (N, frames)
+                assert max_rel(outs[0], outs[1]) < (2e-7 if frames > 8 else 6e-7), (N, frames)
 
 
 @pytest.mark.parametrize("N", [4098, 5000, 10000, 16386, 20000, 50000, 100000, 131070])

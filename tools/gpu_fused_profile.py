@@ -12,8 +12,8 @@ dev = torch.device("cuda:0")
 d_in = rpf.synth.noise_tones_iq_torch(4, N * R, dev)
 d_out = torch.zeros(N, dtype=torch.float64, device=dev)
 s = torch.cuda.current_stream().cuda_stream
-names = ["P wait raw rows", "P first column group", "P wait buffer free", "P second group + stores", "P drain + next raw", "P role barrier + arrive", "-",
-         "C wait produced", "C tile load", "C role barrier + arrive", "C row FFTs + acc", "C role barrier", "-", "-"]
+names = ["P samples -> registers, barrier, next rows' DMA issue", "P both column groups", "P wait: buffer free", "P stores + drain", "P role barrier + arrive", "-", "-",
+         "C wait: round produced", "C tile load -> LDS", "C role barrier + arrive", "C row FFTs + acc", "-", "-", "-"]
 for flags, label in ((rpf._lib.FLAG_FOURSTEP_FUSED, "fused"), (0, "two-kernel")):
     with rpf.Datastore(rpf.Params(N=N, repeats=R), flags=flags) as ds:
         lib = ds._lib
@@ -40,5 +40,5 @@ for flags, label in ((rpf._lib.FLAG_FOURSTEP_FUSED, "fused"), (0, "two-kernel"))
                 print("  %s, per workgroup and round (%d rounds per team), microseconds:" % (role, rounds))
                 for i in range(7):
                     if names[(base and 7) + i] != "-":
-                        print("   %-26s %8.3f  (%4.1f %%)" % (names[(base and 7) + i], prof[base + i] / wgs / rounds / 100.0, 100.0 * prof[base + i] / max(1, tot)))
+                        print("   %-56s %8.3f  (%4.1f %%)" % (names[(base and 7) + i], prof[base + i] / wgs / rounds / 100.0, 100.0 * prof[base + i] / max(1, tot)))
                 print("   total %.3f us per round" % (tot / wgs / rounds / 100.0))
