@@ -56,12 +56,17 @@ typedef struct rpf_config {
 #define RPF_FLAG_NONE 0u
 /* Stage raw bytes through VGPRs instead of LDS-DMA (debug / A-B measurement). */
 #define RPF_FLAG_NO_LDS_DMA 1u
-/* Sizes 16384..262144, TUNING BUILD ONLY (the shipped library fails rpf_engine_create with
- * RPF_ERR_INVALID_ARGUMENT, like RPF_FLAG_VARIANT(k != 0)): the fused persistent four-step kernel
- * (the intermediate stays in the XCDs' L2) instead of the two-kernel path.  Exact and parity-tested,
- * measured slower; a launch whose workgroup teams do not assemble NaN-fills the
- * spectrum and rpf_finish reports RPF_ERR_HARDWARE. */
+/* Sizes 16384..262144 (the four-step sizes): the fused persistent kernel -- ONE launch per acquisition, the
+ * intermediate is handed from the column transforms to the row transforms inside each XCD's L2 instead of crossing
+ * the fabric between two kernels.  It is what these sizes run by default on a 256-CU part (65536 ... 262144; 16384 and
+ * 32768 default to the LDS mixed-radix kernels, so asking for it here is also asking for the four-step path) whenever
+ * its eight workgroup teams assemble at rpf_engine_create; otherwise the engine keeps the two-kernel path.  A launch
+ * whose teams do not assemble later (a CU held by someone else's kernel for ~0.5 s) NaN-fills the spectrum and
+ * rpf_finish reports RPF_ERR_HARDWARE: loud, never wrong.   */
 #define RPF_FLAG_FOURSTEP_FUSED 2u
+/* The four-step sizes on the two-kernel path (intermediate through HBM) even where the fused kernel is available
+ * (A/B measurement, and the fallback's own tests). */
+#define RPF_FLAG_NO_FOURSTEP_FUSED 8u
 /* Sizes served by the LDS mixed-radix kernels (the tables csrc/mixed_plans.inc and
  * csrc/mixed_plans_split.inc: 500, 1000, 3000 ... 80000; 16384, 32768): use the kernel they would
  * get without them -- Bluestein, resp. the four-step pair for 16384 and 32768 (A/B measurement;

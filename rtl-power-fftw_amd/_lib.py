@@ -46,6 +46,7 @@ class rpf_config(ctypes.Structure):
 FLAG_NO_LDS_DMA = 1
 FLAG_FOURSTEP_FUSED = 2
 FLAG_NO_MIXED_RADIX = 4
+FLAG_NO_FOURSTEP_FUSED = 8
 
 # every symbol include/rpf_engine.h declares: (name, restype, argtypes)
 _P = ctypes.c_void_p

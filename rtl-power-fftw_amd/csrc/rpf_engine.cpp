@@ -617,7 +617,7 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         // The fused kernel (one persistent launch, the intermediate stays in each XCD's L2) where
         // the device is the 8 x 32-CU part it is written for and its teams assemble; else K2a/K2b.
         int fused_grid = 0;
-        if ((cfg->flags & RPF_FLAG_FOURSTEP_FUSED) &&
+        if (!(cfg->flags & RPF_FLAG_NO_FOURSTEP_FUSED) &&
             rpf::fourstep_fused_prepare(e->N, e->device, &fused_grid) == hipSuccess) {
             CREATE_TRY(hipMalloc(&e->d_scratch, rpf::fourstep_fused_scratch_bytes(e->N)));
             CREATE_TRY(hipMalloc(&e->d_fused_ctl, rpf::fourstep_fused_ctl_bytes()));

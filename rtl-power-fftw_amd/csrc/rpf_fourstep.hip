@@ -32,6 +32,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
+#include <cstdlib>
 
 #include "rpf_device_common.h"
 #include "rpf_kernels.h"
@@ -306,11 +308,12 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_rows_kernel(const cf* __restr
 // at creation and otherwise keeps K2a/K2b.
 struct FusedCtl {
     unsigned arrivals[8][32];     // [xcd][0]: members registered (own 128-byte line each)
-    // Cumulative counts are safe with ONE buffer per team: a producer arrives for round j only after all 32 consumers of
-    // round j - 1, a consumer for round j only after all 32 producers of round j -- no arrival of a later round can
-    // stand in for a missing one of an earlier round.  (With two buffers it can: 31 of round j + 1 of round j + 1.)
-    unsigned produced[8][32];     // [xcd][0]: producer arrivals, 32 per round
-    unsigned consumed[8][32];     // [xcd][0]: consumer arrivals, 32 per round
+    // One pair of counters per buffer, cumulative over the rounds that use the buffer: a producer arrives for round j only
+    // after all 32 consumers of round j - NBUF, a consumer for round j only after all 32 producers of round j -- no
+    // arrival of a later round of the SAME buffer can stand in for a missing one of an earlier round.  (One counter for
+    // two buffers could: 31 arrivals of round j + 1 of round j + 1 = 32.)
+    unsigned produced[8][2][32];  // [xcd][buffer][0]: producer arrivals, 32 per round
+    unsigned consumed[8][2][32];  // [xcd][buffer][0]: consumer arrivals, 32 per round
     unsigned registered[32];      // [0]: workgroups registered, grid-wide
     unsigned abort[32];           // [0]: != 0 -> results invalid
 };
@@ -338,7 +341,7 @@ __device__ __forceinline__ unsigned l2_read(const unsigned* p)
 struct FusedSync {
     unsigned bar[3];          // [0], [1]: role barriers, monotonically increasing arrival counts (8 per barrier);
                               // [2]: consumer waves that have taken their columns out of the tile (8 per round)
-    unsigned seen[2];         // [0]: `consumed` as last polled by the producers' wave 0; [1]: `produced`, consumers'
+    unsigned seen[2][2];      // [0][buffer]: `consumed` as last polled by the producers' wave 0; [1][buffer]: `produced`, consumers'
     unsigned abort;           // a bounded spin ran out somewhere in this workgroup (or the grid's flag was seen)
     int team[3];              // xcd, rank, ok
 };
@@ -429,14 +432,19 @@ template <class S>
 constexpr int fused_lds_bytes()
 {
     constexpr int slabs = kRoleWaves * (S::SLAB_A + S::SLAB_B) * (int)sizeof(cf);
-    constexpr int raw = S::N1 * (16 * S::SUBA / 2 + 1) * 4;
+    constexpr int raw = S::N1 * 16 * S::SUBA * 2;                        // [N1 rows][2 COLS bytes]: 16 KB
     constexpr int tile = S::N2 * S::ROW_PITCH * (int)sizeof(cf);
     constexpr int twtables = (twlds_entries<typename S::GA>() + twlds_entries<typename S::GB>()) * (int)sizeof(cf);
     constexpr int steptab = 16 * S::SUBA * 8 * (int)sizeof(cf);        // the register-index factor of W_N^{n2 k1}, per column
     return slabs + tile + raw + twtables + steptab;
 }
 
-template <class S, bool WINDOW, bool DMA>
+// NBUF: buffers of Y per team.  1: the round's 2 MB stay in the L2 for good (every read hits, 39 % of the writes never
+// leave: 3.4 x the algorithmic traffic, measured) but every round waits out both hand-offs, 2 x 1.2 - 3.8 us on a busy
+// CU: 0.22 Tsample/s; 2 (shipped): a round's hand-offs hide behind the other buffer's work, 4 MB of Y cycle through a
+// 4 MB L2, all of it is written back once and about two thirds of the reads miss: 0.245.  NT (measurement only): the
+// consumers' tile loads and the raw rows carry the non-temporal hint -- no effect either way (profiles/r04_c4_fused.txt).
+template <class S, bool WINDOW, bool DMA, int NBUF = 2, bool NT = false>
 __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* __restrict__ stream, int nframes,
                                                                const cf* __restrict__ tw_n1,
                                                                const cf* __restrict__ tw_n2,
@@ -452,7 +460,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
     constexpr int TPF = N / 8192;                   // tiles per frame (both steps)
     constexpr int FR = 32 / TPF;                    // frames per round
     constexpr int COLS = 16 * S::SUBA;              // columns per workgroup and round
-    constexpr int PITCH = COLS / 2 + 1;             // dwords per staged raw row (odd: conflict-free column reads)
+    constexpr int ROWB = 2 * COLS;                  // bytes per staged raw row (32 ... 128), unpadded: 16-byte LDS-DMA pieces
     constexpr int GROUPS = 2;                       // column / row groups per wave: 16 groups over 8 waves
     constexpr int RT = S::ROW_TILE, HALF = RT / 2;
     static_assert(TPF >= 1 && TPF <= 32 && N2 / COLS == TPF && N1 / RT == TPF, "tile counts");
@@ -462,8 +470,8 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
     cf* const slabsA = reinterpret_cast<cf*>(smem);                                    // [8][SLAB_A]
     cf* const slabsB = slabsA + kRoleWaves * S::SLAB_A;                                // [8][SLAB_B]
     cf* const tile = slabsB + kRoleWaves * S::SLAB_B;                                  // [N2][ROW_PITCH]
-    uint8_t* const raw = reinterpret_cast<uint8_t*>(tile + N2 * S::ROW_PITCH);         // [N1][PITCH] dwords
-    cf* const twtabA = reinterpret_cast<cf*>(raw + N1 * PITCH * 4);                    // later passes' twiddles, columns
+    uint8_t* const raw = reinterpret_cast<uint8_t*>(tile + N2 * S::ROW_PITCH);         // [N1][ROWB] bytes
+    cf* const twtabA = reinterpret_cast<cf*>(raw + N1 * ROWB);                    // later passes' twiddles, columns
     cf* const twtabB = twtabA + twlds_entries<GA>();                                   // ... and rows
     cf* const steptab = twtabB + twlds_entries<GB>();                                  // [COLS][P]: W_N^{n2 (bin_of(0, a))}
     __shared__ FusedSync sync_;
@@ -493,7 +501,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
         sy->team[1] = static_cast<int>(rank);
         sy->team[2] = ok;
         sy->bar[0] = sy->bar[1] = sy->bar[2] = 0;
-        sy->seen[0] = sy->seen[1] = 0;
+        sy->seen[0][0] = sy->seen[0][1] = sy->seen[1][0] = sy->seen[1][1] = 0;
         sy->abort = 0;
     }
     __syncthreads();                                 // the only workgroup-wide barrier before the output stage
@@ -502,7 +510,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
     const int fsl = rank / TPF, tl = rank % TPF;            // frame slot of the round, tile of the frame
     const int nrounds = (nframes + FR - 1) / FR;
     const int nj = xcd < nrounds ? (nrounds - xcd + 7) / 8 : 0;    // this team's rounds: xcd, xcd + 8, ...
-    cf* const Yteam = Yall + static_cast<size_t>(xcd) * FR * N + static_cast<size_t>(fsl) * N;
+    cf* const Yteam = Yall + static_cast<size_t>(xcd) * NBUF * FR * N + static_cast<size_t>(fsl) * N;     // + (j % NBUF) * FR * N
 
     const bool producer = wave < kRoleWaves;
     const int rw = wave & (kRoleWaves - 1);          // wave inside its role
@@ -533,22 +541,31 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                 if constexpr (WINDOW) wsgn[g][a] = window[static_cast<size_t>(c) * N1 + t0 + TA * a] * ((c & 1) ? -1.0f : 1.0f);
         }
         exchange_sync<false>();              // (steptab rows are written and read by the same lane group)
-        // raw rows of (frame f, tile tl) -> LDS, asynchronously (LDS-DMA) when DMA
+        // Raw rows of (frame f, tile tl) -> LDS in 16-byte pieces, asynchronously (LDS-DMA) when DMA: two instructions
+        // per wave and round.  (Dword pieces into padded rows -- conflict-free column reads -- took 72 LDS-DMA
+        // instructions per workgroup and round, ~1.8 us of the CU's memory pipeline, and every poll of a team counter
+        // queued behind them: the consumers saw `produced` 2.0 - 3.8 us late.  The 8-way bank conflicts of the unpadded
+        // rows cost the sixteen ds_read_u16 of a round ~0.06 us.)
         auto stage_rows = [&](int f) {
             const uint8_t* const frame = stream + static_cast<size_t>(f) * (2 * N);
-#pragma unroll 1
-            for (int i = 0; i < (N1 * PITCH + kRoleThreads - 1) / kRoleThreads; ++i) {
-                const int L = i * kRoleThreads + rtid;
-                const int rr = L / PITCH, d = L % PITCH;
-                if (L < N1 * PITCH && d < COLS / 2) {
-                    const uint8_t* src = frame + 2 * (static_cast<size_t>(N2) * rr + COLS * tl) + 4 * d;
-                    if constexpr (DMA) {
-                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(raw + 4 * (i * kRoleThreads + rw * 64)), 4, 0, 0);
-                    } else {
-                        const uint16_t lo = *reinterpret_cast<const uint16_t*>(src);
-                        const uint16_t hi = *reinterpret_cast<const uint16_t*>(src + 2);
-                        *reinterpret_cast<uint32_t*>(raw + 4 * L) = lo | (static_cast<uint32_t>(hi) << 16);
-                    }
+            constexpr int PPR = ROWB / 16;                      // pieces per row
+            static_assert(N1 * PPR == 2 * kRoleThreads, "two pieces per producer thread");
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int q = i * kRoleThreads + rtid;
+                const uint8_t* src = frame + 2 * (static_cast<size_t>(N2) * (q / PPR) + COLS * tl) + 16 * (q % PPR);
+                if constexpr (DMA) {
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(raw + 16 * (i * kRoleThreads + rw * 64)), 16, 0, 0);
+                } else {
+                    uint16_t h[8];                              // (any even stream address)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) h[k] = *reinterpret_cast<const uint16_t*>(src + 2 * k);
+                    uint4 v;
+                    v.x = h[0] | (static_cast<uint32_t>(h[1]) << 16);
+                    v.y = h[2] | (static_cast<uint32_t>(h[3]) << 16);
+                    v.z = h[4] | (static_cast<uint32_t>(h[5]) << 16);
+                    v.w = h[6] | (static_cast<uint32_t>(h[7]) << 16);
+                    *reinterpret_cast<uint4*>(raw + 16 * q) = v;
                 }
             }
         };
@@ -577,8 +594,8 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                     const int cl = (rw * GROUPS + g) * S::SUBA + sub;
 #pragma unroll
                     for (int a = 0; a < P; a += 2) {
-                        const uint32_t lo = *reinterpret_cast<const uint16_t*>(raw + 4 * ((t + TA * a) * PITCH + (cl >> 1)) + 2 * (cl & 1));
-                        const uint32_t hi = *reinterpret_cast<const uint16_t*>(raw + 4 * ((t + TA * (a + 1)) * PITCH + (cl >> 1)) + 2 * (cl & 1));
+                        const uint32_t lo = *reinterpret_cast<const uint16_t*>(raw + (t + TA * a) * ROWB + 2 * cl);
+                        const uint32_t hi = *reinterpret_cast<const uint16_t*>(raw + (t + TA * (a + 1)) * ROWB + 2 * cl);
                         iq[g][a / 2] = lo | (hi << 16);
                     }
                 }
@@ -618,8 +635,9 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                 }
             }
             FSTAMP(1);                       // both column groups transformed
-            // the team has finished reading the previous round out of the buffer
-            if (j >= 1 && !(alive = team_wait(ctl, sy, &ctl->consumed[xcd][0], &sy->seen[0], 32u * j, rw == 0, lane))) break;
+            // the team has finished reading round j - NBUF out of the buffer
+            if (j >= NBUF && !(alive = team_wait(ctl, sy, &ctl->consumed[xcd][j % NBUF][0], &sy->seen[0][j % NBUF], 32u * (j / NBUF),
+                                                 rw == 0, lane))) break;
             FSTAMP(2);                       // wait: buffer free
             if (valid) {
 #pragma unroll
@@ -630,7 +648,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                         for (int a = 0; a < P; ++a) slab[GA::slot(bin_of<GA>(t, a))] = y0[a];
                         exchange_sync<false>();
                     }
-                    cf* const ycol = Yteam + static_cast<size_t>(c) * RT;      // tile-major, like K2a
+                    cf* const ycol = Yteam + static_cast<size_t>(j % NBUF) * FR * N + static_cast<size_t>(c) * RT;      // tile-major, like K2a
 #pragma unroll
                     for (int a = 0; a < P / 2; ++a) {
                         const int e = 2 * t + 2 * TA * a;
@@ -648,7 +666,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
             FSTAMP(3);                       // stores issued and drained
             if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;
             if (rw == 0 && lane == 0)
-                __hip_atomic_fetch_add(&ctl->produced[xcd][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&ctl->produced[xcd][j % NBUF][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             FSTAMP(4);                       // arrived
         }
         fclk.publish(0, rw == 0 && lane == 0);
@@ -672,10 +690,10 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
         for (int j = 0; j < nj && alive; ++j) {
             const int f = (xcd + 8 * j) * FR + fsl;
             const bool valid = f < nframes;
-            if (!(alive = team_wait(ctl, sy, &ctl->produced[xcd][0], &sy->seen[1], 32u * (j + 1), rw == 0, lane))) break;
+            if (!(alive = team_wait(ctl, sy, &ctl->produced[xcd][j % NBUF][0], &sy->seen[1][j % NBUF], 32u * (j / NBUF + 1), rw == 0, lane))) break;
             FSTAMP(0);                       // wait: round produced
             if (valid) {
-                const cf* const yt = Yteam + static_cast<size_t>(tl) * (N2 * RT);
+                const cf* const yt = Yteam + static_cast<size_t>(j % NBUF) * FR * N + static_cast<size_t>(tl) * (N2 * RT);
                 // sc1 loads: served by the L2, never by this CU's L1 (other CUs wrote these lines); 16 bytes per lane,
                 // all eight of a thread's loads in flight -- and the wait for them in the SAME asm statement: the
                 // compiler does not know that an asm load's destination is written when the data returns, and is free
@@ -685,18 +703,35 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                 const cf* src[PERB];
 #pragma unroll
                 for (int i = 0; i < PERB; ++i) src[i] = yt + 2 * (i * kRoleThreads + rtid);
-                asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
-                             "global_load_dwordx4 %1, %9, off sc1\n\t"
-                             "global_load_dwordx4 %2, %10, off sc1\n\t"
-                             "global_load_dwordx4 %3, %11, off sc1\n\t"
-                             "global_load_dwordx4 %4, %12, off sc1\n\t"
-                             "global_load_dwordx4 %5, %13, off sc1\n\t"
-                             "global_load_dwordx4 %6, %14, off sc1\n\t"
-                             "global_load_dwordx4 %7, %15, off sc1\n\t"
-                             "s_waitcnt vmcnt(0)"
-                             : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-                             : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(src[5]), "v"(src[6]), "v"(src[7])
-                             : "memory");
+                if constexpr (NT) {
+                    asm volatile(
+                        "global_load_dwordx4 %0, %8, off sc1 nt\n\t"
+                        "global_load_dwordx4 %1, %9, off sc1 nt\n\t"
+                        "global_load_dwordx4 %2, %10, off sc1 nt\n\t"
+                        "global_load_dwordx4 %3, %11, off sc1 nt\n\t"
+                        "global_load_dwordx4 %4, %12, off sc1 nt\n\t"
+                        "global_load_dwordx4 %5, %13, off sc1 nt\n\t"
+                        "global_load_dwordx4 %6, %14, off sc1 nt\n\t"
+                        "global_load_dwordx4 %7, %15, off sc1 nt\n\t"
+                        "s_waitcnt vmcnt(0)"
+                        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                        : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(src[5]), "v"(src[6]), "v"(src[7])
+                        : "memory");
+                } else {
+                    asm volatile(
+                        "global_load_dwordx4 %0, %8, off sc1\n\t"
+                        "global_load_dwordx4 %1, %9, off sc1\n\t"
+                        "global_load_dwordx4 %2, %10, off sc1\n\t"
+                        "global_load_dwordx4 %3, %11, off sc1\n\t"
+                        "global_load_dwordx4 %4, %12, off sc1\n\t"
+                        "global_load_dwordx4 %5, %13, off sc1\n\t"
+                        "global_load_dwordx4 %6, %14, off sc1\n\t"
+                        "global_load_dwordx4 %7, %15, off sc1\n\t"
+                        "s_waitcnt vmcnt(0)"
+                        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                        : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(src[5]), "v"(src[6]), "v"(src[7])
+                        : "memory");
+                }
                 // the previous round's columns have left the tile (arrivals posted long ago: see below)
                 if (!(alive = role_wait(sy, 2, static_cast<unsigned>(kRoleWaves) * j))) break;
 #pragma unroll
@@ -711,7 +746,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
             if (!(alive = role_barrier(sy, 1, (nbar += kRoleWaves), lane))) break;
             // every consumer wave's loads have returned: the team may overwrite the buffer
             if (rw == 0 && lane == 0)
-                __hip_atomic_fetch_add(&ctl->consumed[xcd][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&ctl->consumed[xcd][j % NBUF][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             FSTAMP(2);
             if (valid) {
 #pragma unroll
@@ -909,6 +944,9 @@ struct SplitInfo {
     RowsTableFn step_twiddles;   // W_N^{n2 k1} in K2a's lane order
     FusedFn fused[2][2];         // [window][dma]
     int fused_lds, fused_fr;     // LDS bytes; frames per team round
+#ifdef RPF_FUSED_PROFILE
+    FusedFn fused_ab[4];         // measurement only (RPF_FUSED_MODE=0..3, rectangular + LDS-DMA): NBUF 2/2/1/1, NT yes/no/no/yes
+#endif
 };
 
 template <int N1, int N2>
@@ -921,7 +959,12 @@ SplitInfo make_split()
                      fourstep_rows_kernel<S, true>, lane_ordered_rows<typename S::GA>,
                      {{fourstep_fused_kernel<S, false, false>, fourstep_fused_kernel<S, false, true>},
                       {fourstep_fused_kernel<S, true, false>, fourstep_fused_kernel<S, true, true>}},
-                     fused_lds_bytes<S>(), 262144 / S::N};
+                     fused_lds_bytes<S>(), 262144 / S::N,
+#ifdef RPF_FUSED_PROFILE
+                     {fourstep_fused_kernel<S, false, true, 2, true>, fourstep_fused_kernel<S, false, true, 2, false>,
+                      fourstep_fused_kernel<S, false, true, 1, false>, fourstep_fused_kernel<S, false, true, 1, true>}
+#endif
+    };
 }
 
 const SplitInfo kSplits[] = {
@@ -1069,10 +1112,10 @@ hipError_t launch_fourstep(int N, bool window, bool use_dma, const uint8_t* d_st
 }
 
 // ---- fused four-step -----------------------------------------------------------
-size_t fourstep_fused_scratch_bytes(int N)       // Y of one round per XCD: 8 x 2 MB
+size_t fourstep_fused_scratch_bytes(int N)       // Y of two rounds per XCD: 8 x 2 x 2 MB
 {
     const SplitInfo* s = find_split(N);
-    return s ? sizeof(cf) * static_cast<size_t>(s->N) * s->fused_fr * 8 : 0;
+    return s ? sizeof(cf) * static_cast<size_t>(s->N) * s->fused_fr * 8 * 2 : 0;
 }
 int fourstep_fused_slots(int N)
 {
@@ -1116,10 +1159,35 @@ hipError_t launch_fourstep_fused(int N, bool window, bool use_dma, const uint8_t
     if (!s || nframes < 1 || nframes > 0x7fffffffL) return hipErrorInvalidValue;
     hipError_t err = hipMemsetAsync(d_ctl, 0, sizeof(FusedCtl), stream);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(s->fused[window ? 1 : 0][use_dma ? 1 : 0], dim3(256), dim3(kWG), s->fused_lds, stream, d_stream,
-                       static_cast<int>(nframes), d_tw_n1, d_tw_n2, d_twN, d_window, d_scratch, d_partial,
-                       static_cast<FusedCtl*>(d_ctl));
-    return hipGetLastError();
+    FusedFn fn = s->fused[window ? 1 : 0][use_dma ? 1 : 0];
+#ifdef RPF_FUSED_PROFILE
+    if (const char* mode = getenv("RPF_FUSED_MODE"); mode && !window && use_dma) {
+        fn = s->fused_ab[atoi(mode) & 3];
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, s->fused_lds);
+    }
+#endif
+    // One fused launch at a time per device: the kernel needs every CU for itself (one 1024-thread workgroup with all of
+    // the LDS per CU), and two of them dispatched side by side from two streams -- two engines on one device -- could each
+    // hold CUs the other is waiting for until both give up.  Each launch waits for the previous one's event.
+    {
+        int device = 0;
+        if ((err = hipGetDevice(&device)) != hipSuccess) return err;
+        static std::mutex chain_mutex;
+        static hipEvent_t last_launch[64] = {};
+        std::lock_guard<std::mutex> lock(chain_mutex);
+        hipEvent_t& ev = last_launch[device & 63];
+        if (ev) {
+            if ((err = hipStreamWaitEvent(stream, ev, 0)) != hipSuccess) return err;
+        } else if ((err = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) {
+            ev = nullptr;
+            return err;
+        }
+        hipLaunchKernelGGL(fn, dim3(256), dim3(kWG), s->fused_lds, stream, d_stream,
+                           static_cast<int>(nframes), d_tw_n1, d_tw_n2, d_twN, d_window, d_scratch, d_partial,
+                           static_cast<FusedCtl*>(d_ctl));
+        if ((err = hipGetLastError()) != hipSuccess) return err;
+        return hipEventRecord(ev, stream);
+    }
 }
 
 hipError_t launch_fused_poison(const void* d_ctl, double* d_out, int N, hipStream_t stream)

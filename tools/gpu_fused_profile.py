@@ -14,7 +14,7 @@ d_out = torch.zeros(N, dtype=torch.float64, device=dev)
 s = torch.cuda.current_stream().cuda_stream
 names = ["P samples -> registers, barrier, next rows' DMA issue", "P both column groups", "P wait: buffer free", "P stores + drain", "P role barrier + arrive", "-", "-",
          "C wait: round produced", "C tile load -> LDS", "C role barrier + arrive", "C row FFTs + acc", "-", "-", "-"]
-for flags, label in ((rpf._lib.FLAG_FOURSTEP_FUSED, "fused"), (0, "two-kernel")):
+for flags, label in ((rpf._lib.FLAG_FOURSTEP_FUSED, "fused"), (rpf._lib.FLAG_NO_MIXED_RADIX | rpf._lib.FLAG_NO_FOURSTEP_FUSED, "two-kernel")):
     with rpf.Datastore(rpf.Params(N=N, repeats=R), flags=flags) as ds:
         lib = ds._lib
         for _ in range(3):
@@ -31,7 +31,7 @@ for flags, label in ((rpf._lib.FLAG_FOURSTEP_FUSED, "fused"), (0, "two-kernel"))
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / K
         print("%s: %.3f ms per %d frames = %.1f Gsample/s" % (label, ms, R, N * R / ms / 1e6))
-        if flags and hasattr(lib, "rpf_debug_fused_profile"):
+        if flags == rpf._lib.FLAG_FOURSTEP_FUSED and hasattr(lib, "rpf_debug_fused_profile"):
             lib.rpf_debug_fused_profile(prof, 1)
             rounds = (R * N // 262144 + 7) // 8
             for base, role in ((0, "producers"), (8, "consumers")):
@@ -42,3 +42,19 @@ for flags, label in ((rpf._lib.FLAG_FOURSTEP_FUSED, "fused"), (0, "two-kernel"))
                     if names[(base and 7) + i] != "-":
                         print("   %-56s %8.3f  (%4.1f %%)" % (names[(base and 7) + i], prof[base + i] / wgs / rounds / 100.0, 100.0 * prof[base + i] / max(1, tot)))
                 print("   total %.3f us per round" % (tot / wgs / rounds / 100.0))
+
+        if flags == rpf._lib.FLAG_FOURSTEP_FUSED and hasattr(lib, "rpf_debug_fused_trace"):
+            tr = np.zeros((256, 64, 4), dtype=np.uint64)
+            lib.rpf_debug_fused_trace(tr.ctypes.data_as(ctypes.c_void_p))
+            tr = tr.astype(np.int64).reshape(8, 32, 64, 4) / 100.0        # microseconds; [xcd][rank][round][event]
+            x = tr[0]                                                       # team 0 (the trace is of the LAST launch)
+            rounds_ = range(10, 40)
+            pa = x[:, 10:40, 0]; cs = x[:, 10:40, 1]; ca = x[:, 10:40, 2]; ps = x[:, 10:40, 3]
+            print("  hand-offs of team 0, rounds 10..39, microseconds (mean over rounds):")
+            print("   producers' arrivals, last - first CU           %6.2f" % np.mean(pa.max(0) - pa.min(0)))
+            print("   last producer arrival -> first consumer sees   %6.2f   -> last consumer sees %6.2f" % (np.mean(cs.min(0) - pa.max(0)), np.mean(cs.max(0) - pa.max(0))))
+            print("   consumers' arrivals, last - first CU           %6.2f" % np.mean(ca.max(0) - ca.min(0)))
+            print("   consumer sees -> consumer arrives (mean CU)    %6.2f" % np.mean(ca - cs))
+            print("   last consumer arrival -> first producer sees   %6.2f   -> last producer sees %6.2f" % (np.mean(ps[:, 1:].min(0) - ca[:, :-1].max(0)), np.mean(ps[:, 1:].max(0) - ca[:, :-1].max(0))))
+            print("   producer sees -> producer arrives (mean CU)    %6.2f" % np.mean(pa[:, 1:] - ps[:, 1:]))
+            print("   round period                                   %6.2f" % np.mean(np.diff(pa.max(0))))

@@ -52,8 +52,8 @@ while time.time() - t0 < budget:
         N = int(rng.choice(POW2))
     elif fam < 5:
         N = int(rng.choice(FOUR))
-        if rng.integers(0, 2) and "tuning" in os.path.basename(rpf._lib.lib_path()):
-            flags = rpf._lib.FLAG_FOURSTEP_FUSED          # the fused persistent kernel (tuning build only)
+        # the fused persistent kernel (what 65536 ... 262144 run by default; 16384 / 32768 with the flag) or the two-kernel path
+        flags = rpf._lib.FLAG_FOURSTEP_FUSED if rng.integers(0, 2) else rpf._lib.FLAG_NO_MIXED_RADIX | rpf._lib.FLAG_NO_FOURSTEP_FUSED
     elif fam < 7:
         N = 2 * int(rng.integers(1, 2049))
     elif fam < 9:

@@ -2,7 +2,7 @@
 variant.  Usage: python tools/gpu_sweep.py [N:variant ...]
 Variants other than 0 exist only in the tuning build: RPF_ENGINE_LIB=rtl-power-fftw_amd/librpf_engine_tuning.so
 (make -C rtl-power-fftw_amd/csrc tuning).  SWEEP_NOWIN=1 skips the windowed cases, SWEEP_ONLYWIN=1 the plain ones;
-SWEEP_K: timed launches per case (400)."""
+SWEEP_K: timed launches per case (400); SWEEP_FLAGS: RPF_FLAG_* bits for every engine (2 fused four-step, 4 no mixed radix)."""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,7 +37,7 @@ for case in cases:
     for win in ((False,) if os.environ.get("SWEEP_NOWIN") else (True,) if os.environ.get("SWEEP_ONLYWIN") else (False, True)):
         w = rpf.synth.hann_window(N) if win else None
         try:
-            ds = rpf.Datastore(rpf.Params(N=N, window=win, repeats=R), w, flags=(vid << 8))
+            ds = rpf.Datastore(rpf.Params(N=N, window=win, repeats=R), w, flags=(vid << 8) | int(os.environ.get("SWEEP_FLAGS", "0")))
         except rpf.RPFError as ex:
             print("N=%d v=%d win=%d: %s" % (N, vid, win, ex)); continue
         d_pwr = torch.zeros(N, dtype=torch.float64, device=dev)
