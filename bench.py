@@ -257,6 +257,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the reduce even with one rank")
     ap.add_argument("--workload", choices=["auto", "C2", "C3", "C4", "C5"], default="auto")
+    ap.add_argument("--engine-flags", type=int, default=0,
+                    help="RPF_FLAG_* bits for the engine (A/B only, e.g. 8 = C4 on the two-kernel four-step path)")
     ap.add_argument("--shard-as", type=int, default=0,
                     help="(diagnostic) C5: process only the shard rank 0 of a job of this many ranks would own -- "
                          "shows whether the per-step host work keeps up with an 8-GPU step on one GPU; the line's value is then meaningless")
@@ -316,7 +318,8 @@ def main():
     bufs = [base] + [[torch.roll(b, shifts=2 * N * (37 * i)) for b in base] for i in range(1, nb)]
 
     window = rpf.synth.hann_window(N) if wl["window"] else None
-    ds = rpf.Datastore(rpf.Params(N=N, window=window is not None, repeats=R), window, device=dev.index or 0)
+    ds = rpf.Datastore(rpf.Params(N=N, window=window is not None, repeats=R), window, device=dev.index or 0,
+                       flags=args.engine_flags)
     # Exchange: one block = the `hops` spectra of a scan (C5) or of `hops`=8 consecutive
     # acquisitions (C2-C4), reduced onto rank 0 with ONE async RCCL reduce -- fewer, larger collectives --
     # on a ring of blocks so that it overlaps the following steps' kernels.
@@ -498,7 +501,9 @@ def main():
                 except Exception:
                     traffic = None
             kernel = ("fft_accum_kernel<N=4096,P=16> (K1)" if N == 4096 else
-                      "fourstep transform of one acquisition (all batches of the column/row kernels)")
+                      "fourstep transform of one acquisition (two-kernel path: all batches of the column/row kernels)"
+                      if args.engine_flags & 8 else
+                      "fourstep_fused_kernel<Split<512,512>> (one persistent launch per acquisition, Y handed over in the XCDs' L2)")
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "traffic_source": ("NOT measured in this run: rocprofv3 PMC capture replayed from profiles/traffic.json -- "

@@ -2,22 +2,22 @@
 // consumer thread of Datastore (/root/reference/src/datastore.cxx:23-103)
 // re-designed around a HIP device.
 //
-//   producer (caller's thread)                consumer (engine thread)
-//   --------------------------                ------------------------
-//   rpf_buffer_acquire  <-- empty_  <---------  recycle after H2D copy done
-//   fill pinned buffer
-//   rpf_buffer_submit   --> occupied_ ------->  pop everything queued, hipMemcpyAsync H2D
-//                                               (copy stream) back to back
-//                                               into a device staging slot placed so
-//                                               that it continues the byte stream of
-//                                               the previous slot's unfinished frame,
-//                                               fused kernel + reduce (compute stream)
-//   rpf_finish          --> finished_ ------->  drain, sync, pwr -> host, exit
+//   producer (caller's thread)                consumer (engine thread)                  recycler (engine thread)
+//   --------------------------                ------------------------                  ------------------------
+//   rpf_buffer_acquire  <-- empty_  <-------------------------------------------------  each buffer as soon as ITS
+//   fill pinned buffer                                                                   H2D copy has landed
+//   rpf_buffer_submit   --> occupied_ ------->  pop everything queued; per buffer one
+//                                               hipMemcpyAsync H2D, at once, on
+//                                               alternating copy streams, into the
+//                                               device staging slot being filled; when
+//                                               the slot is full (or at the end): carry
+//                                               the previous slot's unfinished frame in
+//                                               front, fused kernel + reduce (compute stream)
+//   rpf_finish          --> finished_ ------->  launch the last slot, sync, pwr -> host, exit
 //
-// Pinned host buffers let the H2D copy of buffer k+1 overlap the kernel of
-// buffer k (two streams + events); a frame that straddles two buffers
-// (datastore.cxx:52,68,81) is completed by copying the tail of the previous
-// staging slot in front of the new bytes, device to device.
+// Pinned host buffers let the H2D copies overlap the kernels (copy streams + compute stream + events); a frame that
+// straddles two slots (datastore.cxx:52,68,81) is completed by copying the tail of the previous staging slot in front
+// of the new bytes, device to device.
 #include "../../include/rpf_engine.h"
 
 #include <hip/hip_runtime_api.h>
@@ -43,11 +43,14 @@ thread_local std::string g_last_error;
 struct HostBuffer {
     uint8_t* data = nullptr;
     size_t size = 0;   // bytes valid after submit (Buffer::size())
+    hipEvent_t copied = nullptr;    // its H2D copy has finished: the producer may refill it
 };
+
+constexpr int kCopyStreams = 2;     // H2D copies alternate between two streams (two SDMA queues): no gap between copies
 
 struct StagingSlot {
     uint8_t* base = nullptr;        // device memory: [head_room | coalesce x buffer_capacity]
-    hipEvent_t copy_done = nullptr; // the group's H2D copies have finished (host buffers reusable)
+    hipEvent_t copy_done[kCopyStreams] = {};   // everything copied into the slot on that stream has landed
     hipEvent_t kernel_done = nullptr;
     bool in_flight = false;
 };
@@ -83,7 +86,13 @@ struct rpf_engine {
     std::string worker_error;
 
     // device side
-    hipStream_t copy_stream = nullptr, compute_stream = nullptr;
+    hipStream_t copy_streams[kCopyStreams] = {}, compute_stream = nullptr;
+    // buffers whose copies are in flight, in issue order; the recycler thread waits for each copy and hands the buffer back
+    std::mutex recycle_mutex;
+    std::condition_variable recycle_cv;
+    std::deque<std::pair<hipEvent_t, HostBuffer*>> recycle_queue;
+    bool recycle_stop = false;
+    std::string recycler_error;
     rpf::cf* d_twiddles = nullptr;
     bool fourstep = false;                // N handled by rpf_fourstep.hip
     bool fused = false;                   // ... by the fused persistent kernel (Y stays in the XCDs' L2)
@@ -275,6 +284,35 @@ int launch_frames(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, doubl
     return RPF_OK;
 }
 
+// Hands the pool's buffers back to the producer, each as soon as ITS copy has landed (datastore.cxx:91-94 returns a
+// buffer when the worker is done with it; here "done" is the end of the H2D copy, not of the transform).  A thread of
+// its own so that the consumer thread never blocks on a copy while new buffers are waiting to be issued: with five
+// 1.6 MB buffers a blocking consumer alternated 4-buffer and 1-buffer groups and left the link idle between them
+// (37 GB/s of the 54.5 GB/s large buffers reach).
+void recycler_main(rpf_engine* e)
+{
+    (void)hipSetDevice(e->device);
+    std::unique_lock<std::mutex> lk(e->recycle_mutex);
+    for (;;) {
+        e->recycle_cv.wait(lk, [&]() { return !e->recycle_queue.empty() || e->recycle_stop; });
+        if (e->recycle_queue.empty()) break;                     // stop requested and everything handed back
+        const std::pair<hipEvent_t, HostBuffer*> item = e->recycle_queue.front();
+        e->recycle_queue.pop_front();
+        lk.unlock();
+        if (item.first) {
+            const hipError_t err = hipEventSynchronize(item.first);
+            if (err != hipSuccess && e->recycler_error.empty())
+                e->recycler_error = std::string("hipEventSynchronize(copied): ") + hipGetErrorString(err);
+        }
+        {
+            std::lock_guard<std::mutex> status(e->status_mutex);
+            e->empty_buffers.push_back(item.second);             // datastore.cxx:91-94
+            e->status_change.notify_all();
+        }
+        lk.lock();
+    }
+}
+
 // Consumer thread: the GPU counterpart of Datastore::fftThread.
 void worker_main(rpf_engine* e)
 {
@@ -295,116 +333,125 @@ void worker_main(rpf_engine* e)
         }                                               \
     } while (0)
     WORKER_TRY(hipSetDevice(e->device), "hipSetDevice");
+    {
+        std::lock_guard<std::mutex> lk(e->recycle_mutex);
+        e->recycle_stop = false;
+        e->recycler_error.clear();
+    }
+    std::thread recycler(recycler_main, e);
+    auto hand_back = [&](HostBuffer* b, hipEvent_t copied) {
+        std::lock_guard<std::mutex> lk(e->recycle_mutex);
+        e->recycle_queue.emplace_back(copied, b);
+        e->recycle_cv.notify_one();
+    };
 
     const size_t frame_bytes = 2 * static_cast<size_t>(e->N);
+    const size_t slot_bytes = e->coalesce * e->buffer_capacity;
     size_t carry = 0;             // bytes of an unfinished frame at the end of the previous slot
     const uint8_t* carry_src = nullptr;
     size_t slot_idx = 0;
     int64_t frames_issued = 0;    // == repeats_done once everything has drained
-    std::vector<HostBuffer*> group;
-    // The previous group's host buffers are handed back only after the next group's
-    // copies have been issued (when there is a next group already waiting), so the
-    // PCIe link does not idle for a host wake-up between groups.
-    std::vector<HostBuffer*> copying;
-    hipEvent_t copying_done = nullptr;
-    auto recycle = [&]() {
-        if (copying.empty()) return;
-        if (copying_done) WORKER_TRY(hipEventSynchronize(copying_done), "hipEventSynchronize(copy_done)");
-        std::lock_guard<std::mutex> lk(e->status_mutex);
-        for (HostBuffer* b : copying) e->empty_buffers.push_back(b);   // datastore.cxx:91-94
-        copying.clear();
-        copying_done = nullptr;
-        e->status_change.notify_all();
+    // The staging slot being filled: buffers are copied into it one by one as the producer submits them -- each copy
+    // issued at once, on alternating copy streams -- and ONE transform is launched over the slot when it is full or the
+    // acquisition ends; the stream the kernels see is the concatenation of the buffers in FIFO order either way.
+    StagingSlot* cur = nullptr;
+    size_t off = 0;               // bytes copied into `cur`
+    bool used[kCopyStreams] = {};
+    unsigned next_stream = 0;
+
+    auto open_slot = [&]() {
+        cur = &e->staging[slot_idx];
+        slot_idx = (slot_idx + 1) % e->staging.size();
+        // The slot is free once its own kernel AND the following slot's carry copy (which read its tail) are done;
+        // the latter precedes that slot's kernel_done in stream order.
+        StagingSlot& after = e->staging[slot_idx];
+        for (StagingSlot* s : {cur, &after}) {
+            if (!s->in_flight) continue;
+            WORKER_TRY(hipEventSynchronize(s->kernel_done), "hipEventSynchronize(kernel_done)");
+            s->in_flight = false;
+        }
+        off = 0;
+        for (bool& u : used) u = false;
+    };
+    auto launch_slot = [&]() {
+        if (!cur) return;
+        // new bytes sit right after the head room; the carried partial frame goes immediately in front of them
+        uint8_t* const dst = cur->base + e->head_room;
+        for (int c = 0; c < kCopyStreams; ++c) {
+            if (!used[c]) continue;
+            WORKER_TRY(hipEventRecord(cur->copy_done[c], e->copy_streams[c]), "hipEventRecord(copy_done)");
+            WORKER_TRY(hipStreamWaitEvent(e->compute_stream, cur->copy_done[c], 0), "hipStreamWaitEvent");
+        }
+        if (carry)
+            WORKER_TRY(hipMemcpyAsync(dst - carry, carry_src, carry, hipMemcpyDeviceToDevice, e->compute_stream),
+                       "hipMemcpyAsync(carry)");
+        const size_t avail = carry + off;
+        int64_t nframes = static_cast<int64_t>(avail / frame_bytes);
+        nframes = std::min<int64_t>(nframes, e->repeats - frames_issued);    // datastore.cxx:67
+        if (ok() && nframes > 0) {
+            int rc = launch_frames(e, dst - carry, nframes, e->d_pwr, /*accumulate=*/true, e->compute_stream);
+            if (rc != RPF_OK) {
+                e->worker_rc = rc;
+                e->worker_error = e->last_error;
+            }
+            frames_issued += nframes;
+        }
+        WORKER_TRY(hipEventRecord(cur->kernel_done, e->compute_stream), "hipEventRecord(kernel_done)");
+        cur->in_flight = ok();
+        // the unfinished frame (if any) stays in this slot until the next one is launched
+        const size_t consumed = static_cast<size_t>(std::max<int64_t>(nframes, 0)) * frame_bytes;
+        carry = (frames_issued < e->repeats) ? (avail - consumed) % frame_bytes : 0;
+        carry_src = dst + off - carry;
+        cur = nullptr;
+        off = 0;
     };
 
+    std::vector<HostBuffer*> batch;
     std::unique_lock<std::mutex> status_lock(e->status_mutex, std::defer_lock);
     while (true) {
         // Wait until we have a bufferful of data (datastore.cxx:54-64)
         status_lock.lock();
-        if (e->occupied_buffers.empty() && !copying.empty()) {
-            // nothing queued: the producer may be waiting for the very buffers we hold
-            status_lock.unlock();
-            recycle();
-            status_lock.lock();
-        }
         while (e->occupied_buffers.empty() && !e->acquisition_finished)
             e->status_change.wait(status_lock);
         if (e->occupied_buffers.empty()) {
             status_lock.unlock();
             break;   // acquisition finished
         }
-        // Everything the producer has queued so far (up to the staging slot's capacity)
-        // goes to the device as one group: copies back to back, ONE transform launch --
-        // the stream is the concatenation of the buffers in FIFO order either way.
-        group.clear();
-        while (!e->occupied_buffers.empty() && group.size() < e->coalesce) {
-            group.push_back(e->occupied_buffers.front());
-            e->occupied_buffers.pop_front();
-        }
+        batch.assign(e->occupied_buffers.begin(), e->occupied_buffers.end());
+        e->occupied_buffers.clear();
         status_lock.unlock();
 
-        size_t total = 0;
-        for (HostBuffer* b : group) total += b->size;
-        // datastore.cxx:67: once the quota is met the rest of the stream is ignored
-        if (e->worker_rc == RPF_OK && frames_issued < e->repeats && total > 0) {
-            StagingSlot& slot = e->staging[slot_idx];
-            slot_idx = (slot_idx + 1) % e->staging.size();
-            // The slot is free once its own kernel AND the next group's carry copy
-            // (which read its tail) are done; the latter precedes the next slot's
-            // kernel_done in stream order.
-            StagingSlot& after = e->staging[slot_idx];
-            for (StagingSlot* s : {&slot, &after}) {
-                if (!s->in_flight) continue;
-                WORKER_TRY(hipEventSynchronize(s->kernel_done), "hipEventSynchronize(kernel_done)");
-                s->in_flight = false;
+        for (HostBuffer* b : batch) {
+            // datastore.cxx:67: once the quota is met (by what is staged already) the rest of the stream is ignored
+            const int64_t staged = frames_issued + static_cast<int64_t>((carry + off) / frame_bytes);
+            if (!ok() || b->size == 0 || staged >= e->repeats) {
+                hand_back(b, nullptr);
+                continue;
             }
-            // new bytes go right after the head room; the carried partial frame
-            // is placed immediately in front of them
-            uint8_t* dst = slot.base + e->head_room;
-            size_t off = 0;
-            for (HostBuffer* b : group) {
-                if (b->size == 0) continue;
-                WORKER_TRY(hipMemcpyAsync(dst + off, b->data, b->size, hipMemcpyHostToDevice, e->copy_stream),
-                           "hipMemcpyAsync(H2D)");
-                off += b->size;
-            }
-            WORKER_TRY(hipEventRecord(slot.copy_done, e->copy_stream), "hipEventRecord(copy_done)");
-            if (carry)
-                WORKER_TRY(hipMemcpyAsync(dst - carry, carry_src, carry, hipMemcpyDeviceToDevice, e->compute_stream),
-                           "hipMemcpyAsync(carry)");
-            WORKER_TRY(hipStreamWaitEvent(e->compute_stream, slot.copy_done, 0), "hipStreamWaitEvent");
-
-            const size_t avail = carry + total;
-            int64_t nframes = static_cast<int64_t>(avail / frame_bytes);
-            nframes = std::min<int64_t>(nframes, e->repeats - frames_issued);
-            if (e->worker_rc == RPF_OK && nframes > 0) {
-                int rc = launch_frames(e, dst - carry, nframes, e->d_pwr, /*accumulate=*/true,
-                                       e->compute_stream);
-                if (rc != RPF_OK) {
-                    e->worker_rc = rc;
-                    e->worker_error = e->last_error;
-                }
-                frames_issued += nframes;
-            }
-            WORKER_TRY(hipEventRecord(slot.kernel_done, e->compute_stream), "hipEventRecord(kernel_done)");
-            slot.in_flight = ok();
-            // the unfinished frame (if any) stays in this slot until the next group
-            const size_t consumed = static_cast<size_t>(nframes) * frame_bytes;
-            carry = (frames_issued < e->repeats) ? (avail - consumed) % frame_bytes : 0;
-            carry_src = dst + total - carry;
-            // the pinned buffers may be refilled as soon as their H2D copies are done:
-            // the previous group's now (its copies precede ours on the copy stream, and
-            // ours are already queued behind them), this group's one iteration later
-            recycle();
-            copying = group;
-            copying_done = ok() ? slot.copy_done : nullptr;
-        } else {
-            recycle();
-            copying = group;          // nothing was copied: returned at the next recycle()
-            copying_done = nullptr;
+            if (cur && off + b->size > slot_bytes) launch_slot();
+            if (!cur) open_slot();
+            const unsigned c = next_stream;
+            next_stream = (next_stream + 1) % kCopyStreams;
+            WORKER_TRY(hipMemcpyAsync(cur->base + e->head_room + off, b->data, b->size, hipMemcpyHostToDevice, e->copy_streams[c]),
+                       "hipMemcpyAsync(H2D)");
+            WORKER_TRY(hipEventRecord(b->copied, e->copy_streams[c]), "hipEventRecord(copied)");
+            used[c] = true;
+            off += b->size;
+            hand_back(b, ok() ? b->copied : nullptr);
         }
     }
-    recycle();
+    launch_slot();   // what the last, partly filled slot holds
+
+    {
+        std::lock_guard<std::mutex> lk(e->recycle_mutex);
+        e->recycle_stop = true;
+        e->recycle_cv.notify_one();
+    }
+    recycler.join();             // every buffer is back in empty_buffers
+    if (ok() && !e->recycler_error.empty()) {
+        e->worker_rc = RPF_ERR_HARDWARE;
+        e->worker_error = e->recycler_error;
+    }
 
     WORKER_TRY(hipStreamSynchronize(e->compute_stream), "hipStreamSynchronize");
     if (e->fused && ok()) {
@@ -438,12 +485,16 @@ void release_device(rpf_engine* e)
     for (auto& s : e->staging) {
         if (s.base) (void)hipFree(s.base);
         if (s.kernel_done) (void)hipEventDestroy(s.kernel_done);
-        if (s.copy_done) (void)hipEventDestroy(s.copy_done);
+        for (hipEvent_t ev : s.copy_done)
+            if (ev) (void)hipEventDestroy(ev);
     }
-    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    for (hipStream_t cs : e->copy_streams)
+        if (cs) (void)hipStreamDestroy(cs);
     if (e->compute_stream) (void)hipStreamDestroy(e->compute_stream);
-    for (auto& b : e->pool)
+    for (auto& b : e->pool) {
         if (b.data) (void)hipHostFree(b.data);
+        if (b.copied) (void)hipEventDestroy(b.copied);
+    }
 }
 
 }  // namespace
@@ -531,7 +582,7 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
 
     DeviceScope on_device(e->device);       // the caller's current device is restored on return
     CREATE_TRY(on_device.status());
-    CREATE_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    for (hipStream_t& cs : e->copy_streams) CREATE_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     CREATE_TRY(hipStreamCreateWithFlags(&e->compute_stream, hipStreamNonBlocking));
 
     // "plan": twiddle table on the device (where fftwf_plan_dft_1d stands, datastore.cxx:32)
@@ -681,19 +732,21 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         CREATE_TRY(hipHostMalloc(&p, e->buffer_capacity, hipHostMallocDefault));
         b.data = static_cast<uint8_t*>(p);
         b.size = e->buffer_capacity;
+        CREATE_TRY(hipEventCreateWithFlags(&b.copied, hipEventDisableTiming));
         e->empty_buffers.push_back(&b);
     }
     // device staging ring: head room for a carried partial frame + one buffer
     e->head_room = ((2 * static_cast<size_t>(e->N)) + 255) / 256 * 256;
-    // a slot holds as many queued buffers as fit 64 MB (at least one, at most the pool)
-    e->coalesce = std::max<size_t>(1, std::min<size_t>(e->n_buffers, (64u << 20) / e->buffer_capacity));
+    // a slot (= one transform launch) holds as many buffers as fit 32 MB, at least one -- more than the pool has where the
+    // buffers are small: they return to the producer when their copy lands, not when the slot is launched
+    e->coalesce = std::max<size_t>(1, (32u << 20) / e->buffer_capacity);
     e->staging.resize(3);
     for (auto& s : e->staging) {
         void* p = nullptr;
         CREATE_TRY(hipMalloc(&p, e->head_room + e->coalesce * e->buffer_capacity));
         s.base = static_cast<uint8_t*>(p);
         CREATE_TRY(hipEventCreateWithFlags(&s.kernel_done, hipEventDisableTiming));
-        CREATE_TRY(hipEventCreateWithFlags(&s.copy_done, hipEventDisableTiming));
+        for (hipEvent_t& ev : s.copy_done) CREATE_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
 #undef CREATE_TRY
     *out = e;

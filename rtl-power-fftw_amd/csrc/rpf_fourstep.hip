@@ -317,6 +317,14 @@ struct FusedCtl {
     unsigned registered[32];      // [0]: workgroups registered, grid-wide
     unsigned abort[32];           // [0]: != 0 -> results invalid
 };
+#ifdef RPF_FUSED_PROFILE
+// measurement knobs (rpf_debug_fused_knobs): [0] poll pause 0: s_sleep 2, 1: none, 2: s_sleep 8; [1] every wave of a role
+// polls the L2 itself; [2] consumers skip their transforms; [3] producers skip theirs (results are garbage with 2, 3)
+__device__ int g_fused_knob[4];
+#define FKNOB(i) g_fused_knob[i]
+#else
+#define FKNOB(i) 0
+#endif
 constexpr unsigned kSpinLimit = 4u << 20;      // global polls of ~0.1-3 us: >= 0.5 s
 constexpr unsigned kLdsSpinLimit = 1u << 26;   // LDS polls of ~50 ns
 
@@ -382,14 +390,15 @@ __device__ __forceinline__ bool team_wait(FusedCtl* ctl, FusedSync* sy, const un
 {
     if (__hip_atomic_load(seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) return true;
     unsigned spins = 0;
-    if (poller) {
+    if (poller || FKNOB(1)) {
         for (;;) {
             const unsigned v = __builtin_amdgcn_readfirstlane(l2_read(counter));
             if (v >= target) {
                 if (lane == 0) __hip_atomic_store(seen, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 return true;
             }
-            __builtin_amdgcn_s_sleep(2);
+            if (FKNOB(0) == 0) __builtin_amdgcn_s_sleep(2);
+            else if (FKNOB(0) == 2) __builtin_amdgcn_s_sleep(8);
             if (++spins > kSpinLimit || __hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ||
                 ((spins & 255u) == 0 && ctl_load(&ctl->abort[0]) != 0)) {
                 if (lane == 0) {
@@ -411,6 +420,7 @@ __device__ __forceinline__ bool team_wait(FusedCtl* ctl, FusedSync* sy, const un
 // of a round to g_fused_prof (tools/gpu_fused_profile.py prints them); never in the shipped library.
 #ifdef RPF_FUSED_PROFILE
 __device__ unsigned long long g_fused_prof[16];
+
 struct FusedClock {
     unsigned long long last, sum[8];
     __device__ __forceinline__ void start() { for (int i = 0; i < 8; ++i) sum[i] = 0; last = wall_clock64(); }
@@ -621,7 +631,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                         if constexpr (WINDOW) x[a] = (v - (kTwo23 + 127.0f)) * wsgn[g][a];
                         else x[a] = v * sgn + off;
                     }
-                    group_fft_twlds<GA>(t, x, tw, slab, twtabA);
+                    if (!FKNOB(3)) group_fft_twlds<GA>(t, x, tw, slab, twtabA);
                     exchange_sync<false>();
                     if (g == 0) {
 #pragma unroll
@@ -759,7 +769,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                     // next round's tile write waits for all eight arrivals, by then long posted -- a barrier behind the
                     // transforms, where the waves are skewed, cost 1.5 us per round
                     if (g == GROUPS - 1) role_arrive(sy, 2, lane);
-                    group_fft_twlds<GB>(t, x, tw, slab, twtabB);
+                    if (!FKNOB(2)) group_fft_twlds<GB>(t, x, tw, slab, twtabB);
                     phase_accumulate(x, acc[g], P);
                     exchange_sync<false>();
                 }
@@ -806,6 +816,10 @@ __global__ void fused_poison_kernel(const FusedCtl* __restrict__ ctl, double* __
 #ifdef RPF_FUSED_PROFILE
 }  // namespace
 }  // namespace rpf
+extern "C" int rpf_debug_fused_knobs(const int* four)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(rpf::g_fused_knob), four, sizeof(int) * 4) == hipSuccess ? 0 : 1;
+}
 extern "C" int rpf_debug_fused_profile(unsigned long long* out16, int reset)
 {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rpf::g_fused_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;

@@ -12,7 +12,7 @@
 //    workgroup, twiddle placement) that measured fastest on the GPU (tools/gen_mixed_plans.py,
 //    tools/pick_mixed_plans.py, profiles/r02_mixed_plan_search.txt).  0.25 ... 1.06 Tsample/s.
 //  * mixed_split_kernel (same header; its tables are compiled in rpf_mixed_split.hip): N = P M, P = 2 ... 5, M even
-//    with factors 2 ... 25 (mixed_plans_split.inc: 53 sizes, 10500 ... 80000): workgroup b computes the residue p of the spectrum,
+//    with factors 2 ... 25 (mixed_plans_split.inc: 54 sizes, 10500 ... 108000): workgroup b computes the residue p of the spectrum,
 //    X[p + P k] = FFT_M(x'_p)[k], so only raw bytes cross workgroups.  0.14 ... 0.47 Tsample/s.
 //  * mixed_kernel: any other even N <= 5120 with prime factors 2, 3, 5, runtime plan: Stockham
 //    autosort, decimation in frequency, one radix (5, 4, 3, 2) per pass, natural order in and

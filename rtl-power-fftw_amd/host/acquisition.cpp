@@ -30,7 +30,11 @@ std::string Acquisition::utc_now()
 {
     const time_t now = std::time(nullptr);
     char text[80];
-    std::strftime(text, sizeof(text), "%Y-%m-%d %X UTC", std::gmtime(&now));
+    // gmtime_r: several acquisitions run side by side under --gpus a,b,... and std::gmtime hands every caller the same
+    // static struct tm (ThreadSanitizer found the race, profiles/r04_tsan.txt)
+    struct tm parts;
+    gmtime_r(&now, &parts);
+    std::strftime(text, sizeof(text), "%Y-%m-%d %X UTC", &parts);
     return text;
 }
 

@@ -17,6 +17,9 @@ names = ["P samples -> registers, barrier, next rows' DMA issue", "P both column
 for flags, label in ((rpf._lib.FLAG_FOURSTEP_FUSED, "fused"), (rpf._lib.FLAG_NO_MIXED_RADIX | rpf._lib.FLAG_NO_FOURSTEP_FUSED, "two-kernel")):
     with rpf.Datastore(rpf.Params(N=N, repeats=R), flags=flags) as ds:
         lib = ds._lib
+        if hasattr(lib, "rpf_debug_fused_knobs") and os.environ.get("RPF_FUSED_KNOBS"):
+            kn = (ctypes.c_int * 4)(*[int(v) for v in os.environ["RPF_FUSED_KNOBS"].split(",")])
+            lib.rpf_debug_fused_knobs(kn)
         for _ in range(3):
             ds.accumulate_device(d_in.data_ptr(), 2 * N * R, R, d_out.data_ptr(), s)
         torch.cuda.synchronize()

@@ -14,7 +14,17 @@
 
 #include "../include/rpf_engine.h"
 
+#include <cmath>
+
 static int failures = 0;
+// the same stream twice: equal up to the grouping of the f64 partial sums (which launch a frame lands in)
+static bool same(const std::vector<double>& a, const std::vector<double>& b)
+{
+    if (a.size() != b.size()) return false;
+    for (size_t i = 0; i < a.size(); ++i)
+        if (std::fabs(a[i] - b[i]) > 1e-12 * std::fabs(a[i])) return false;
+    return true;
+}
 #define EXPECT(c) do { if (!(c)) { printf("FAILED: %s (line %d)\n", #c, __LINE__); ++failures; } } while (0)
 
 static std::vector<uint8_t> make_stream(size_t bytes, uint64_t seed)
@@ -75,7 +85,7 @@ int main()
         EXPECT(feed(e, s, 16382, 73, &first, N) == 73);
         for (int k = 0; k < 2; ++k) {
             EXPECT(feed(e, s, 16382, 73, &again, N) == 73);
-            EXPECT(first == again);
+            EXPECT(same(first, again));
         }
         // (2) unget, then an early finish
         EXPECT(rpf_begin(e, 1000) == RPF_OK);
@@ -105,7 +115,7 @@ int main()
         int64_t da = 0, db = 0;
         EXPECT(rpf_accumulate(e, s.data(), s.size(), frames, a.data(), &da) == RPF_OK && da == frames);
         EXPECT(rpf_accumulate(e, s.data(), s.size(), frames, b.data(), &db) == RPF_OK && db == frames);
-        EXPECT(a == b);
+        EXPECT(same(a, b));
         rpf_engine_destroy(e);
     }
     {   // (5) two engines, two producer threads
@@ -120,7 +130,7 @@ int main()
         std::thread t1([&]() { for (int k = 0; k < 3; ++k) d1 = feed(e1, s, 65536, 400, &p1, N); });
         t0.join();
         t1.join();
-        EXPECT(d0 == 400 && d1 == 400 && p0 == p1);
+        EXPECT(d0 == 400 && d1 == 400 && same(p0, p1));
         rpf_engine_destroy(e0);
         rpf_engine_destroy(e1);
     }
