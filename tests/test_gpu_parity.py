@@ -186,14 +186,16 @@ def test_split_mixed_radix_sizes_match_oracle(N, torch_dev):
         assert max_rel(few[filled], few_truth[filled]) < 2 * PARITY
 
 
-THIN_MARGIN_SIZES = [16384, 20000, 24000, 25000, 30000, 32000, 32768, 36000, 40000, 45000, 48000, 50000, 60000, 64000, 75000,
+THIN_MARGIN_SIZES = [16384, 20000, 24000, 25000, 30000, 32000, 32768, 36000, 40000, 45000, 48000, 50000, 60000,
                      80000, 131072, 262144, 524288,
                      # round 3's split-form sizes (mixed_plans_split.inc, second block)
                      10500, 11500, 13500, 14000, 17000, 18000, 19000, 21000, 22000, 23000, 26000, 27000, 28000, 33000, 34000,
-                     35000, 38000, 39000, 42000, 44000, 46000, 49000, 51000, 52000, 54000, 55000, 56000, 57000, 63000, 65000,
-                     66000, 68000, 69000, 70000, 72000, 76000, 77000, 78000,
+                     35000, 38000, 39000, 42000, 44000, 46000, 49000, 51000, 54000, 55000, 56000, 57000, 63000, 65000,
+                     66000, 68000, 69000, 70000, 78000,
                      # ... and the paired form's (third block)
-                     81000, 81920, 88000, 90000, 92000, 96000, 98304, 100000, 104000, 105000, 108000]
+                     81000, 81920, 88000, 92000, 96000, 104000, 108000]
+# (round 4: 52000, 64000, 72000, 75000, 76000, 77000, 90000, 98304, 100000, 105000 failed the held-out streams of
+#  test_gpu_heldout.py and left the split-form table; they are no longer picked sizes)
 
 
 @pytest.mark.parametrize("N", THIN_MARGIN_SIZES)

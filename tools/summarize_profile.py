@@ -61,6 +61,8 @@ def classify(name):
         return "K1_fft_accum"
     if "reduce_kernel" in name:
         return "K3_reduce"
+    if "fourstep_fused_kernel" in name:
+        return "K2f_fused"
     if "fourstep_cols_kernel" in name:
         return "K2a_cols"
     if "fourstep_rows_kernel" in name:
@@ -142,6 +144,18 @@ for sub in ("c4_pmc_FETCH_SIZE", "c4_pmc_WRITE_SIZE"):
             c4.setdefault(k + "_totals", {})[c] = {"sum_KiB": s, "launches": n}
 out["C4_fourstep"] = c4
 try:
+    # round 4: ONE launch of the fused kernel per acquisition (+ one proof launch per engine, 16 frames, at creation)
+    fz = c4["K2f_fused_totals"]
+    acq = fz["FETCH_SIZE"]["launches"] - 1
+    acq_w = fz["WRITE_SIZE"]["launches"] - 1
+    traffic["fourstep_c4_fetch_bytes_per_launch"] = fz["FETCH_SIZE"]["sum_KiB"] * 1024.0 * 2.0 / acq
+    traffic["fourstep_c4_write_bytes_per_launch"] = fz["WRITE_SIZE"]["sum_KiB"] * 1024.0 / acq_w
+    traffic["fourstep_c4_hbm_bytes_per_launch"] = (traffic["fourstep_c4_fetch_bytes_per_launch"] +
+                                                   traffic["fourstep_c4_write_bytes_per_launch"])
+    traffic["fourstep_c4_note"] = ("per acquisition of 1000 frames = one launch of the fused four-step kernel; Y is written back once and "
+                                   "about two thirds of its reads miss the L2 (two buffers of Y per team)")
+except (KeyError, ZeroDivisionError):
+  try:
     acq = c4["K2b_rows_totals"]["FETCH_SIZE"]["launches"] / C4_BATCHES
     fetch = (c4["K2a_cols_totals"]["FETCH_SIZE"]["sum_KiB"] + c4["K2b_rows_totals"]["FETCH_SIZE"]["sum_KiB"]) * 1024.0 * 2.0 / acq
     acq_w = c4["K2b_rows_totals"]["WRITE_SIZE"]["launches"] / C4_BATCHES
@@ -150,7 +164,7 @@ try:
     traffic["fourstep_c4_write_bytes_per_launch"] = write
     traffic["fourstep_c4_hbm_bytes_per_launch"] = fetch + write
     traffic["fourstep_c4_note"] = "per acquisition of 1000 frames = one launch of K2a + one of K2b; the intermediate Y is written and read once"
-except (KeyError, ZeroDivisionError):
+  except (KeyError, ZeroDivisionError):
     pass
 
 hb = os.path.join(src, "hbm_read.txt")
