@@ -109,6 +109,8 @@ struct rpf_engine {
     rpf::cf* d_tw_sub = nullptr;          // four-step: twiddles of the N1-point column transforms
     rpf::cf* d_tw_sub2 = nullptr;         // four-step: twiddles of the N2-point row transforms
     rpf::cf* d_scratch = nullptr;         // four-step: intermediate Y
+    size_t scratch_bytes = 0;             // its size now; grown on demand (two-kernel four-step and large Bluestein paths)
+    size_t scratch_per_frame = 0, scratch_max = 0;
     rpf::cf* d_step2 = nullptr;           // large Bluestein: second transform's inter-step twiddles
     float* d_window = nullptr;
     double* d_partial = nullptr;
@@ -226,6 +228,33 @@ int launch_fused_hops(rpf_engine* e, const uint8_t* const* d_frames, const int64
     return RPF_OK;
 }
 
+// The intermediate of the two-kernel four-step and large Bluestein paths: sized to what the launches need, not to the
+// 2 GB (4 GB) a whole device-resident acquisition can use -- a queue-fed engine never launches more than a 32 MB slot
+// of input.  Grows (never shrinks) when a larger launch arrives: one stream synchronisation, then free + allocate; if
+// the device cannot give more the launch runs in smaller batches on what there is.
+int ensure_scratch(rpf_engine* e, int64_t nframes, hipStream_t stream)
+{
+    if (!e->scratch_per_frame) return RPF_OK;
+    const size_t want = std::min<size_t>(e->scratch_max, static_cast<size_t>(nframes) * e->scratch_per_frame);
+    if (want <= e->scratch_bytes) return RPF_OK;
+    HIP_TRY(e, hipStreamSynchronize(stream));
+    HIP_TRY(e, hipStreamSynchronize(e->compute_stream));
+    const size_t had = e->scratch_bytes;
+    (void)hipFree(e->d_scratch);
+    e->d_scratch = nullptr;
+    e->scratch_bytes = 0;
+    void* p = nullptr;
+    if (hipMalloc(&p, want) == hipSuccess) {
+        e->scratch_bytes = want;
+    } else {
+        (void)hipGetLastError();
+        HIP_TRY(e, hipMalloc(&p, had));
+        e->scratch_bytes = had;
+    }
+    e->d_scratch = static_cast<rpf::cf*>(p);
+    return RPF_OK;
+}
+
 // Enqueue K1 (or the four-step pair K2a/K2b) for `nframes` frames starting at
 // d_frames; leaves *nslots partial spectra in e->d_partial.
 int launch_transform(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, hipStream_t stream,
@@ -243,8 +272,9 @@ int launch_transform(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, hi
     }
     if (e->fourstep) {
         const bool dma = e->use_dma && (addr % 4) == 0;
+        if (int rc = ensure_scratch(e, nframes, stream)) return rc;
         HIP_TRY(e, rpf::launch_fourstep(e->N, e->has_window, dma, d_frames, nframes, e->d_tw_sub,
-                                        e->d_tw_sub2, e->d_twiddles, e->d_window, e->d_scratch,
+                                        e->d_tw_sub2, e->d_twiddles, e->d_window, e->d_scratch, e->scratch_bytes,
                                         e->d_partial, e->plan.grid, stream));
         e->last = e->plan;
         *nslots = rpf::fourstep_partial_slots(e->N);
@@ -259,8 +289,9 @@ int launch_transform(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, hi
     }
     if (e->bigblu) {
         const bool dma = e->use_dma && (addr % 4) == 0;
+        if (int rc = ensure_scratch(e, nframes, stream)) return rc;
         HIP_TRY(e, rpf::launch_bigblu(e->N, dma, d_frames, nframes, e->d_tw_sub, e->d_tw_sub2, e->d_twiddles,
-                                      e->d_step2, e->d_chirp, e->d_bhat, e->d_scratch, e->d_partial,
+                                      e->d_step2, e->d_chirp, e->d_bhat, e->d_scratch, e->scratch_bytes, e->d_partial,
                                       e->plan.grid, stream));
         e->last = e->plan;
         *nslots = rpf::bigblu_partial_slots(e->N);
@@ -659,7 +690,11 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         rpf::make_twiddles(blu_m2, tws);
         CREATE_TRY(hipMalloc(&e->d_tw_sub2, sizeof(rpf::cf) * tws.size()));
         CREATE_TRY(hipMemcpy(e->d_tw_sub2, tws.data(), sizeof(rpf::cf) * tws.size(), hipMemcpyHostToDevice));
-        CREATE_TRY(hipMalloc(&e->d_scratch, rpf::bigblu_scratch_bytes(e->N)));
+        // (the intermediate starts at 256 MB and grows with the launches: ensure_scratch)
+        e->scratch_per_frame = rpf::bigblu_scratch_bytes_per_frame(e->N);
+        e->scratch_max = rpf::bigblu_scratch_bytes(e->N);
+        e->scratch_bytes = std::min<size_t>(e->scratch_max, std::max<size_t>(e->scratch_per_frame, static_cast<size_t>(256) << 20));
+        CREATE_TRY(hipMalloc(&e->d_scratch, e->scratch_bytes));
         partial_slots = rpf::bigblu_partial_slots(e->N);
         partial_len = e->blu_M;
         // the kernels read chirp, kernel spectrum and inter-step twiddles in their own lane order
@@ -696,7 +731,10 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
             partial_slots = rpf::fourstep_fused_slots(e->N);
         } else {
             (void)hipGetLastError();
-            CREATE_TRY(hipMalloc(&e->d_scratch, rpf::fourstep_scratch_bytes(e->N)));
+            e->scratch_per_frame = rpf::fourstep_scratch_bytes_per_frame(e->N);
+            e->scratch_max = rpf::fourstep_scratch_bytes(e->N);
+            e->scratch_bytes = std::min<size_t>(e->scratch_max, static_cast<size_t>(256) << 20);
+            CREATE_TRY(hipMalloc(&e->d_scratch, e->scratch_bytes));
             partial_slots = rpf::fourstep_partial_slots(e->N);
         }
         // K2a reads the inter-step twiddles and the window in its own lane order
@@ -740,7 +778,10 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
             e->d_scratch = nullptr;
             (void)hipFree(e->d_partial);
             e->d_partial = nullptr;
-            CREATE_TRY(hipMalloc(&e->d_scratch, rpf::fourstep_scratch_bytes(e->N)));
+            e->scratch_per_frame = rpf::fourstep_scratch_bytes_per_frame(e->N);
+            e->scratch_max = rpf::fourstep_scratch_bytes(e->N);
+            e->scratch_bytes = std::min<size_t>(e->scratch_max, static_cast<size_t>(256) << 20);
+            CREATE_TRY(hipMalloc(&e->d_scratch, e->scratch_bytes));
             CREATE_TRY(hipMalloc(&e->d_partial, sizeof(double) * e->N * std::max<size_t>(partial_slots, rpf::fourstep_partial_slots(e->N))));
         }
     }

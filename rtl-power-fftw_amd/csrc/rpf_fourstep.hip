@@ -354,6 +354,19 @@ struct FusedSync {
     int team[3];              // xcd, rank, ok
 };
 
+// The same word through the SCALAR memory path (s_load_dword glc: past the scalar cache, to the L2): a queue of its own,
+// not behind the CU's vector-memory traffic.  Measurement knob 0 = 3 (profile build).
+__device__ __forceinline__ unsigned l2_read_scalar(const unsigned* p)
+{
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(a));
+    const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(a >> 32));
+    const unsigned long long ua = (static_cast<unsigned long long>(hi) << 32) | lo;
+    unsigned r;
+    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(ua) : "memory");
+    return r;
+}
+
 // Barrier among the 8 waves of one role (no s_barrier: that one spans both roles).  `target` = 8 x the number of
 // this role's barriers so far.  LDS operations of one wave execute in order, so the arrival follows its writes.
 // (split form: role_arrive where the wave is done, role_wait where it needs the others -- nothing stalls in between)
@@ -392,12 +405,12 @@ __device__ __forceinline__ bool team_wait(FusedCtl* ctl, FusedSync* sy, const un
     unsigned spins = 0;
     if (poller || FKNOB(1)) {
         for (;;) {
-            const unsigned v = __builtin_amdgcn_readfirstlane(l2_read(counter));
+            const unsigned v = FKNOB(0) == 3 ? l2_read_scalar(counter) : __builtin_amdgcn_readfirstlane(l2_read(counter));
             if (v >= target) {
                 if (lane == 0) __hip_atomic_store(seen, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 return true;
             }
-            if (FKNOB(0) == 0) __builtin_amdgcn_s_sleep(2);
+            if (FKNOB(0) == 0 || FKNOB(0) == 3) __builtin_amdgcn_s_sleep(2);
             else if (FKNOB(0) == 2) __builtin_amdgcn_s_sleep(8);
             if (++spins > kSpinLimit || __hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ||
                 ((spins & 255u) == 0 && ctl_load(&ctl->abort[0]) != 0)) {
@@ -1043,6 +1056,11 @@ size_t fourstep_scratch_bytes(int N)
     const SplitInfo* s = find_split(N);
     return s ? sizeof(cf) * static_cast<size_t>(s->N) * s->batch : 0;
 }
+size_t fourstep_scratch_bytes_per_frame(int N)
+{
+    const SplitInfo* s = find_split(N);
+    return s ? sizeof(cf) * static_cast<size_t>(s->N) : 0;
+}
 
 int fourstep_partial_slots(int N)
 {
@@ -1101,15 +1119,18 @@ hipError_t fourstep_prepare(int N, int device, LaunchInfo* li)
 
 hipError_t launch_fourstep(int N, bool window, bool use_dma, const uint8_t* d_stream, long nframes,
                            const cf* d_tw_n1, const cf* d_tw_n2, const cf* d_twN, const float* d_window,
-                           cf* d_scratch, double* d_partial, int max_grid, hipStream_t stream)
+                           cf* d_scratch, size_t scratch_bytes, double* d_partial, int max_grid, hipStream_t stream)
 {
     const SplitInfo* s = find_split(N);
     if (!s || nframes < 1) return hipErrorInvalidValue;
+    // frames per launch pair: what the scratch the engine has grown so far holds (at most the compile-time batch)
+    const long batch = std::min<long>(s->batch, static_cast<long>(scratch_bytes / (sizeof(cf) * static_cast<size_t>(s->N))));
+    if (batch < 1) return hipErrorInvalidValue;
     const int rows_grid = s->row_tiles * s->groups;
     const ColsFn cols = s->cols[window ? 1 : 0][use_dma ? 1 : 0];
     bool first = true;
-    for (long done = 0; done < nframes; done += s->batch) {
-        const int nb = static_cast<int>(std::min<long>(s->batch, nframes - done));
+    for (long done = 0; done < nframes; done += batch) {
+        const int nb = static_cast<int>(std::min<long>(batch, nframes - done));
         const uint8_t* src = d_stream + static_cast<size_t>(done) * 2 * s->N;
         const int cols_grid = std::min(max_grid, nb * (s->N2 / kColTile));
         hipLaunchKernelGGL(cols, dim3(cols_grid), dim3(kWG), s->cols_lds, stream, src, nb, d_tw_n1, d_twN,
@@ -1255,6 +1276,11 @@ size_t bigblu_scratch_bytes(int N)      // Y and Y2, one after the other
     const BluSplitInfo* s = find_blu_split(N);
     return s ? 2 * sizeof(cf) * static_cast<size_t>(s->M) * s->batch : 0;
 }
+size_t bigblu_scratch_bytes_per_frame(int N)
+{
+    const BluSplitInfo* s = find_blu_split(N);
+    return s ? 2 * sizeof(cf) * static_cast<size_t>(s->M) : 0;
+}
 
 int bigblu_partial_slots(int N)
 {
@@ -1289,16 +1315,19 @@ hipError_t bigblu_prepare(int N, int device, LaunchInfo* li)
 
 hipError_t launch_bigblu(int N, bool use_dma, const uint8_t* d_stream, long nframes, const cf* d_tw_m1,
                          const cf* d_tw_m2, const cf* d_step_tw, const cf* d_step_tw2, const cf* d_g_t,
-                         const cf* d_bhat_t, cf* d_scratch, double* d_partial, int max_grid, hipStream_t stream)
+                         const cf* d_bhat_t, cf* d_scratch, size_t scratch_bytes, double* d_partial, int max_grid,
+                         hipStream_t stream)
 {
     const BluSplitInfo* s = find_blu_split(N);
     if (!s || nframes < 1) return hipErrorInvalidValue;
+    const long batch = std::min<long>(s->batch, static_cast<long>(scratch_bytes / (2 * sizeof(cf) * static_cast<size_t>(s->M))));
+    if (batch < 1) return hipErrorInvalidValue;
     cf* const Y = d_scratch;
-    cf* const Y2 = d_scratch + static_cast<size_t>(s->M) * s->batch;
+    cf* const Y2 = d_scratch + static_cast<size_t>(s->M) * batch;
     const int rows_grid = s->row_tiles * s->groups;
     bool first = true;
-    for (long done = 0; done < nframes; done += s->batch) {
-        const int nb = static_cast<int>(std::min<long>(s->batch, nframes - done));
+    for (long done = 0; done < nframes; done += batch) {
+        const int nb = static_cast<int>(std::min<long>(batch, nframes - done));
         const uint8_t* src = d_stream + static_cast<size_t>(done) * 2 * N;
         const int cols_grid = std::min(max_grid, nb * (s->M2 / kColTile));
         hipLaunchKernelGGL(s->cols[use_dma ? 1 : 0], dim3(cols_grid), dim3(kWG), s->cols_lds, stream, src, nb,

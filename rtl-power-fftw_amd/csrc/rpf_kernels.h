@@ -72,7 +72,8 @@ hipError_t launch_bluestein(int N, const uint8_t* d_stream, long nframes, const 
 
 // ---- four-step path (rpf_fourstep.hip): N = N1 x N2, powers of two 16384..262144 --
 bool fourstep_supported(int N);
-size_t fourstep_scratch_bytes(int N);  // the intermediate of one launch pair: 2 GB of complex floats, tile-major (rpf_fourstep.hip)
+size_t fourstep_scratch_bytes(int N);  // the LARGEST intermediate of one launch pair: 2 GB of complex floats, tile-major (rpf_fourstep.hip)
+size_t fourstep_scratch_bytes_per_frame(int N);   // the engine grows its scratch to what its launches need, up to the above
 int fourstep_partial_slots(int N);     // partial spectra written by K2b (frame groups)
 int fourstep_sub_lengths(int N, int* n1, int* n2);
 // Host tables in the kernels' lane order: step_tw[n2][.] = W_N^{n2 k1} (N entries),
@@ -84,10 +85,10 @@ hipError_t fourstep_prepare(int N, int device, LaunchInfo* li);
 // d_twN / d_window: fourstep_tables' step_tw / window_t.
 hipError_t launch_fourstep(int N, bool window, bool use_dma, const uint8_t* d_stream, long nframes,
                            const cf* d_tw_n1, const cf* d_tw_n2, const cf* d_twN, const float* d_window,
-                           cf* d_scratch, double* d_partial, int max_grid, hipStream_t stream);
+                           cf* d_scratch, size_t scratch_bytes, double* d_partial, int max_grid, hipStream_t stream);
 
 // ---- fused four-step (rpf_fourstep.hip): one persistent kernel, Y stays in each XCD's L2 --------
-size_t fourstep_fused_scratch_bytes(int N);   // 16 MB: one 2 MB round of Y per XCD
+size_t fourstep_fused_scratch_bytes(int N);   // 32 MB: two 2 MB rounds of Y per XCD
 int fourstep_fused_slots(int N);              // partial spectra written: 8 teams x frames per round
 size_t fourstep_fused_ctl_bytes();
 // fails (hipErrorInvalidValue) unless the device has 256 CUs and one workgroup fits a CU
@@ -102,7 +103,8 @@ hipError_t fourstep_fused_aborted(const void* d_ctl, hipStream_t stream, bool* a
 // ---- large Bluestein path (rpf_fourstep.hip): even N in (4096, 131072], not a power of two --
 bool bigblu_supported(int N);
 int bigblu_lengths(int N, int* M, int* m1, int* m2);   // M = m1 * m2 = 2^ceil(log2(2N-1))
-size_t bigblu_scratch_bytes(int N);    // two intermediates of 2 GB
+size_t bigblu_scratch_bytes(int N);    // two intermediates of 2 GB at most
+size_t bigblu_scratch_bytes_per_frame(int N);
 int bigblu_partial_slots(int N);       // partial spectra of M (not N) doubles each
 hipError_t bigblu_prepare(int N, int device, LaunchInfo* li);
 // Host tables (each M entries, in the kernels' lane order) from bluestein_tables.h's g (N) and bhat (M).
@@ -111,7 +113,8 @@ void bigblu_tables(int N, const cf* g, const cf* bhat, std::vector<cf>& g_t, std
 // d_tw_m1 / d_tw_m2: master twiddles of lengths m1, m2; the rest: bigblu_tables' outputs.
 hipError_t launch_bigblu(int N, bool use_dma, const uint8_t* d_stream, long nframes, const cf* d_tw_m1,
                          const cf* d_tw_m2, const cf* d_step_tw, const cf* d_step_tw2, const cf* d_g_t,
-                         const cf* d_bhat_t, cf* d_scratch, double* d_partial, int max_grid, hipStream_t stream);
+                         const cf* d_bhat_t, cf* d_scratch, size_t scratch_bytes, double* d_partial, int max_grid,
+                         hipStream_t stream);
 
 // ---- generic path (rpf_generic.hip): every other even N -- powers of two up to 2^26, others up to 2^23 --
 bool generic_supported(int N);

@@ -303,6 +303,45 @@ def test_fused_four_step_equals_the_two_kernel_path(N, torch_dev):
                 assert (max_rel(outs[0], outs[1]) < 5e-7) if frames > 64 else (max_err_over_mean(outs[0], outs[1]) < 2e-6), (N, frames, max_rel(outs[0], outs[1]), max_err_over_mean(outs[0], outs[1]))
 
 
+def test_two_fused_engines_on_one_device_from_two_threads(torch_dev):
+    """The fused four-step kernel needs every CU for itself; two engines on one device launching it from two threads
+    and two streams at once must not starve each other into giving up (their launches are serialised through a
+    per-device event chain).  Results against a lone engine's, bit for bit; a misaligned d_pwr_out is refused."""
+    import threading
+    import torch
+    N, R = 65536, 400
+    stream = rpf.synth.uniform_iq(91, N * R)
+    d_in = torch.from_numpy(stream).to(torch_dev)
+    with rpf.Datastore(rpf.Params(N=N, repeats=R)) as lone:
+        want, _ = run_device(lone, stream, R, torch_dev)
+        d_bad = torch.zeros(N + 2, dtype=torch.float64, device=torch_dev)
+        with pytest.raises(rpf.RPFError) as e:      # the reduce stores bin pairs: 16-byte alignment (include/rpf_engine.h)
+            lone.accumulate_device(d_in.data_ptr(), stream.size, R, d_bad.data_ptr() + 8, 0)
+        assert e.value.retval == rpf.ReturnValue.InvalidArgument
+    outs, errors = {}, []
+
+    def work(k):
+        try:
+            s = torch.cuda.Stream(device=torch_dev)
+            with rpf.Datastore(rpf.Params(N=N, repeats=R)) as ds:
+                d_out = torch.empty(N, dtype=torch.float64, device=torch_dev)
+                for _ in range(12):
+                    assert ds.accumulate_device(d_in.data_ptr(), stream.size, R, d_out.data_ptr(), s.cuda_stream) == R
+                s.synchronize()
+                outs[k] = d_out.cpu().numpy()
+        except Exception as exc:                      # (an assertion in a thread would otherwise vanish)
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        assert np.all(np.isfinite(outs[k])) and np.array_equal(outs[k], want)
+
+
 @pytest.mark.parametrize("N", [4098, 5000, 10000, 16386, 20000, 50000, 100000, 131070])
 def test_large_non_power_of_two_sizes_match_oracle(N, torch_dev):
     """Even N in (4096, 131072] that is not a power of two: Bluestein through the
