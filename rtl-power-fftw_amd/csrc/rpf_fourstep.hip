@@ -355,7 +355,9 @@ struct FusedSync {
 };
 
 // The same word through the SCALAR memory path (s_load_dword glc: past the scalar cache, to the L2): a queue of its own,
-// not behind the CU's vector-memory traffic.  Measurement knob 0 = 3 (profile build).
+// not behind the CU's vector-memory traffic -- where a poll otherwise waits out the CU's own tile loads, Y stores and
+// LDS-DMA (measured in the profile build: + 3 % with two buffers of Y per team, + 16 % with one).  What the shipped
+// kernel polls with; the vector form stays for measurement (knob 0 = 4).
 __device__ __forceinline__ unsigned l2_read_scalar(const unsigned* p)
 {
     const unsigned long long a = reinterpret_cast<unsigned long long>(p);
@@ -405,12 +407,12 @@ __device__ __forceinline__ bool team_wait(FusedCtl* ctl, FusedSync* sy, const un
     unsigned spins = 0;
     if (poller || FKNOB(1)) {
         for (;;) {
-            const unsigned v = FKNOB(0) == 3 ? l2_read_scalar(counter) : __builtin_amdgcn_readfirstlane(l2_read(counter));
+            const unsigned v = FKNOB(0) == 4 ? __builtin_amdgcn_readfirstlane(l2_read(counter)) : l2_read_scalar(counter);
             if (v >= target) {
                 if (lane == 0) __hip_atomic_store(seen, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 return true;
             }
-            if (FKNOB(0) == 0 || FKNOB(0) == 3) __builtin_amdgcn_s_sleep(2);
+            if (FKNOB(0) == 0 || FKNOB(0) == 4) __builtin_amdgcn_s_sleep(2);
             else if (FKNOB(0) == 2) __builtin_amdgcn_s_sleep(8);
             if (++spins > kSpinLimit || __hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ||
                 ((spins & 255u) == 0 && ctl_load(&ctl->abort[0]) != 0)) {
@@ -467,7 +469,10 @@ constexpr int fused_lds_bytes()
 // CU: 0.22 Tsample/s; 2 (shipped): a round's hand-offs hide behind the other buffer's work, 4 MB of Y cycle through a
 // 4 MB L2, all of it is written back once and about two thirds of the reads miss: 0.245.  NT (measurement only): the
 // consumers' tile loads and the raw rows carry the non-temporal hint -- no effect either way (profiles/r04_c4_fused.txt).
-template <class S, bool WINDOW, bool DMA, int NBUF = 2, bool NT = false>
+#ifndef RPF_FUSED_NBUF
+#define RPF_FUSED_NBUF 2
+#endif
+template <class S, bool WINDOW, bool DMA, int NBUF = RPF_FUSED_NBUF, bool NT = false>
 __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* __restrict__ stream, int nframes,
                                                                const cf* __restrict__ tw_n1,
                                                                const cf* __restrict__ tw_n2,

@@ -8,14 +8,13 @@
 //
 // One persistent launch, one 256-thread workgroup per CU (96 KB of LDS requested so that no two share a CU).
 // The workgroups that find themselves on one XCD (HW_REG_XCC_ID) form a team: ranks 0-7 write, 8-15 read,
-// 16-23 either idle or stream a "foreign" 2 MB table through the same L2 (what the 2 MB W_N table did to the
-// round-2 fused kernel).  Per round: writers store the team's buffer (16 B per lane, pattern = f(round, index)),
+// 16-31 idle (the ALL-32 rows below use every workgroup).  Per round: writers store the team's buffer (16 B per lane, pattern = f(round, index)),
 // drain (s_waitcnt vmcnt(0)), arrive on the team's `produced` counter; readers wait for all writers, apply the
 // acquire under test, read the whole buffer with 8 x 16 B loads in flight per lane, count words that do not
 // carry this round's pattern (= stale reads), arrive on `consumed`; writers wait for that before the next round.
 // The counters are touched only by L2-executed atomics.  Every spin is bounded.
 //
-// Each (store flavour, load flavour, foreign, cross) combination is its own kernel NAME so that rocprofv3's
+// Each (store flavour, load flavour, -, cross) combination is its own kernel NAME so that rocprofv3's
 // per-kernel counters can be read apart.  CROSS = readers read the buffer of XCD (x+1)%8: the calibration row
 // (those reads cannot be L2 hits; FETCH_SIZE must show footprint x rounds, in whatever unit it really counts).
 #include <hip/hip_runtime.h>
@@ -136,7 +135,10 @@ __device__ __forceinline__ u4 pattern(unsigned round, unsigned idx)
     return u4{h, h ^ 0xdeadbeefu, round, idx};
 }
 
-// bytes: the team's buffer (a multiple of 4096); buf: 8 such buffers 16 MB apart; table: 8 x 2 MB foreign tables.
+// bytes: the team's buffer (a multiple of 4096); buf: 8 such buffers 16 MB apart; table, sink: unused.
+// (FOREIGN: a third group of workgroups streaming a 2 MB table through the same L2 was tried and removed -- its sweep
+//  faulted on this stack, and the round-4 fused kernel has no such stream; the parameter stays for the kernel names in
+//  profiles/r04_l2_residency_raw.txt)
 template <int ST, int LD, bool FOREIGN, bool CROSS>
 __global__ __launch_bounds__(256) void residency_kernel(u4* __restrict__ buf, size_t bytes, int rounds,
                                                         const u4* __restrict__ table, Ctl* __restrict__ ctl, unsigned* sink, int stage)
@@ -222,24 +224,6 @@ __global__ __launch_bounds__(256) void residency_kernel(u4* __restrict__ buf, si
             ctl->stale[32 * xcd + rank] = wg_bad;
             ctl->ticks[32 * xcd + rank] = cyc;
         }
-    } else if (FOREIGN && rank < kWriters + kReaders + 8) {
-        // one sweep of this XCD's 2 MB table per round, unsynchronised; 8 workgroups share it
-        const u4* const tb = table + static_cast<size_t>(xcd) * ((2u << 20) / 16);
-        const int fr = rank - kWriters - kReaders;
-        unsigned acc = 0;
-        for (int r = 0; r < rounds; ++r) {
-            for (int c0 = fr; c0 < 512; c0 += 8 * 8) {
-                u4 v[8];
-                const u4* p[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) p[u] = tb + static_cast<unsigned>(c0 + 8 * u) * 256u + tid;
-                load8<LD_PLAIN_NOINV>(v, p);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc ^= v[u].x;
-            }
-            if (__hip_atomic_load(&ctl->abort_[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        }
-        if (acc == 0x12345678u) *sink = acc;
     }
 }
 
@@ -335,9 +319,6 @@ static const Variant kVariants[] = {
     V(ST_NT, LD_INV_PLAIN, false, false, "nt stores, buffer_inv sc1 + plain loads"),
     V(ST_SC1, LD_SC1, false, false, "sc1 stores, sc1 loads"),
     V(ST_SC0SC1, LD_SC0SC1, false, false, "sc0 sc1 stores, sc0 sc1 loads"),
-    // (the FOREIGN rows -- a third group of workgroups streaming a 2 MB table through the same L2, what the W_N table did
-    //  to the round-2 fused kernel -- fault in their sweep on this stack and are left out: the round-4 fused kernel keeps
-    //  its step twiddles in registers and has no such stream)
     V(ST_SC1, LD_SC1, false, true, "CROSS-XCD calibration: sc1 stores, sc1 loads of the NEXT XCD's buffer"),
     V32(ST_PLAIN, LD_SC1, "ALL 32 CUs write, then read a neighbour's share: plain stores, sc1 loads"),
     V32(ST_PLAIN, LD_INV_PLAIN, "ALL 32 CUs write, then read a neighbour's share: plain stores, buffer_inv sc1 + plain loads"),
