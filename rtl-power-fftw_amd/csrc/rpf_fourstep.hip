@@ -435,6 +435,11 @@ __device__ __forceinline__ bool team_wait(FusedCtl* ctl, FusedSync* sy, const un
 // of a round to g_fused_prof (tools/gpu_fused_profile.py prints them); never in the shipped library.
 #ifdef RPF_FUSED_PROFILE
 __device__ unsigned long long g_fused_prof[16];
+// absolute 100 MHz time stamps of the hand-offs, [workgroup = 32 xcd + rank][round < 64][event]: 0 producers arrived,
+// 1 consumers saw `produced`, 2 consumers arrived, 3 producers saw `consumed` (tools/gpu_fused_profile.py prints
+// where the signals spend their time)
+__device__ unsigned long long g_fused_trace[256][64][4];
+#define FTRACE(ev) do { if (rw == 0 && lane == 0 && j < 64) g_fused_trace[32 * xcd + rank][j][ev] = wall_clock64(); } while (0)
 
 struct FusedClock {
     unsigned long long last, sum[8];
@@ -449,6 +454,7 @@ struct FusedClock {
     __device__ __forceinline__ void publish(int, bool) {}
 };
 #define FSTAMP(i) ((void)0)
+#define FTRACE(ev) ((void)0)
 #endif
 
 constexpr int kRoleWaves = kWaves / 2, kRoleThreads = kRoleWaves * 64;
@@ -666,6 +672,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
             // the team has finished reading round j - NBUF out of the buffer
             if (j >= NBUF && !(alive = team_wait(ctl, sy, &ctl->consumed[xcd][j % NBUF][0], &sy->seen[0][j % NBUF], 32u * (j / NBUF),
                                                  rw == 0, lane))) break;
+            FTRACE(3);
             FSTAMP(2);                       // wait: buffer free
             if (valid) {
 #pragma unroll
@@ -695,6 +702,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
             if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;
             if (rw == 0 && lane == 0)
                 __hip_atomic_fetch_add(&ctl->produced[xcd][j % NBUF][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            FTRACE(0);
             FSTAMP(4);                       // arrived
         }
         fclk.publish(0, rw == 0 && lane == 0);
@@ -719,6 +727,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
             const int f = (xcd + 8 * j) * FR + fsl;
             const bool valid = f < nframes;
             if (!(alive = team_wait(ctl, sy, &ctl->produced[xcd][j % NBUF][0], &sy->seen[1][j % NBUF], 32u * (j / NBUF + 1), rw == 0, lane))) break;
+            FTRACE(1);
             FSTAMP(0);                       // wait: round produced
             if (valid) {
                 const cf* const yt = Yteam + static_cast<size_t>(j % NBUF) * FR * N + static_cast<size_t>(tl) * (N2 * RT);
@@ -775,6 +784,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
             // every consumer wave's loads have returned: the team may overwrite the buffer
             if (rw == 0 && lane == 0)
                 __hip_atomic_fetch_add(&ctl->consumed[xcd][j % NBUF][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            FTRACE(2);
             FSTAMP(2);
             if (valid) {
 #pragma unroll
@@ -834,6 +844,10 @@ __global__ void fused_poison_kernel(const FusedCtl* __restrict__ ctl, double* __
 #ifdef RPF_FUSED_PROFILE
 }  // namespace
 }  // namespace rpf
+extern "C" int rpf_debug_fused_trace(unsigned long long* out)      // 256 x 64 x 4 values
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(rpf::g_fused_trace), sizeof(unsigned long long) * 256 * 64 * 4) == hipSuccess ? 0 : 1;
+}
 extern "C" int rpf_debug_fused_knobs(const int* four)
 {
     return hipMemcpyToSymbol(HIP_SYMBOL(rpf::g_fused_knob), four, sizeof(int) * 4) == hipSuccess ? 0 : 1;
