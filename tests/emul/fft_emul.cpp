@@ -523,3 +523,26 @@ extern "C" int rpf_emul_walk_hops(const int64_t* nframes, int H, int fpw, int ma
     if (iterations != a.total) return -15;
     return grid;
 }
+
+// The fused four-step kernel (rpf_fourstep.hip) factors the inter-step twiddle W_N^{c bin_of(t, a)} into a per-lane
+// register W_N^{c bin_of(t, 0)} and a per-register LDS value W_N^{c bin_of(0, a)}: that needs
+// bin_of(t, a) == bin_of(t, 0) + bin_of(0, a) for every lane and register of the column geometries it runs
+// (Geom<128 | 256 | 512, 8>: the digits of 8 t + a do not carry).  Returns the number of (t, a) that break it.
+template <class G>
+static int bin_split_violations()
+{
+    int bad = 0;
+    for (int t = 0; t < G::T; ++t)
+        for (int a = 0; a < G::P; ++a)
+            if (rpf::bin_of<G>(t, a) != rpf::bin_of<G>(t, 0) + rpf::bin_of<G>(0, a)) ++bad;
+    return bad;
+}
+extern "C" int rpf_emul_fused_bin_split(int n1)
+{
+    switch (n1) {
+        case 128: return bin_split_violations<rpf::Geom<128, 8>>();
+        case 256: return bin_split_violations<rpf::Geom<256, 8>>();
+        case 512: return bin_split_violations<rpf::Geom<512, 8>>();
+        default: return -1;
+    }
+}

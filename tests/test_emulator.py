@@ -116,3 +116,15 @@ def test_every_shipped_mixed_radix_plan_on_the_emulator():
         assert np.all(np.isfinite(got)), N
         # two frames: little averaging, so against max(bin, mean bin) like the other small cases
         assert max_err_over_mean(got, truth_f64(N, stream, R, w)) < 2e-6, N
+
+
+@pytest.mark.parametrize("n1", [128, 256, 512])
+def test_fused_four_step_twiddle_factorisation_holds(n1):
+    """rpf_fourstep.hip's fused kernel keeps W_N^{c bin_of(t, a)} as (per-lane register) x (per-register LDS value):
+    valid only while bin_of(t, a) = bin_of(t, 0) + bin_of(0, a) for its column geometries."""
+    import ctypes
+    from helpers import emul_lib
+    lib = emul_lib()
+    lib.rpf_emul_fused_bin_split.argtypes = [ctypes.c_int]
+    assert lib.rpf_emul_fused_bin_split(n1) == 0
+    assert lib.rpf_emul_fused_bin_split(64) == -1

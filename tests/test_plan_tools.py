@@ -41,3 +41,27 @@ def test_picker_rule():
     assert pick.choose([fast_inaccurate, soft, ok_fast, ok]) == ok_fast  # the fastest within the limit
     assert pick.choose([fast_inaccurate, (200.0, 6.2e-7, "e")]) == (200.0, 6.2e-7, "e")      # fallback
     assert pick.choose([fast_inaccurate]) is None
+
+
+def test_no_tool_knows_the_held_out_streams():
+    """tests/test_gpu_heldout.py holds every picked size to the parity bar on two streams derived from a constant that
+    lives in that file only.  No plan picker, scorer or generator under tools/ may import it, name it or restate its
+    formulas -- the one tool that reads it, gpu_heldout_alternatives.py, measures the kernels that take a failed size
+    BACK (large Bluestein, the two-kernel pair) and chooses no plan."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "tests", "test_gpu_heldout.py")).read()
+    key = re.search(r"HELD_OUT_KEY = (0x[0-9A-Fa-f_]+)", text).group(1)
+    for path in glob.glob(os.path.join(root, "tools", "*")):
+        if not os.path.isfile(path) or os.path.basename(path) == "gpu_heldout_alternatives.py":
+            continue
+        try:
+            body = open(path, errors="ignore").read()
+        except OSError:
+            continue
+        low = body.lower()
+        assert key.lower() not in low and key.replace("_", "").lower() not in low, path
+        assert "test_gpu_heldout" not in body and "held_out_seeds" not in body and "HELD_OUT_KEY" not in body, path
+    alt = open(os.path.join(root, "tools", "gpu_heldout_alternatives.py")).read()
+    assert "pick" not in alt.lower().replace("picks nothing", "") and "mixed_plans" not in alt
