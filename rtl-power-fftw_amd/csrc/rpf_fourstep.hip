@@ -318,12 +318,17 @@ struct FusedCtl {
     unsigned abort[32];           // [0]: != 0 -> results invalid
 };
 #ifdef RPF_FUSED_PROFILE
-// measurement knobs (rpf_debug_fused_knobs): [0] poll pause 0: s_sleep 2, 1: none, 2: s_sleep 8; [1] every wave of a role
-// polls the L2 itself; [2] consumers skip their transforms; [3] producers skip theirs (results are garbage with 2, 3)
+// measurement knobs (rpf_debug_fused_knobs): [0] poll pause 0: s_sleep 2, 1: none, 2: s_sleep 8, 4: vector-path polls;
+// [1] 1: tiles rotated by half a frame against the team ranks, 2: the tiles' places in Y rotated, 3: no raw rows (garbage
+// in), 5 / 6: the raw rows' LDS-DMA issued after the column transforms; [2] consumers skip their transforms; [3] producers
+// skip theirs (results are garbage with 2, 3)
 __device__ int g_fused_knob[4];
 #define FKNOB(i) g_fused_knob[i]
 #else
-#define FKNOB(i) 0
+#ifndef RPF_FUSED_KNOB1
+#define RPF_FUSED_KNOB1 0
+#endif
+#define FKNOB(i) ((i) == 1 ? RPF_FUSED_KNOB1 : 0)      // (make fexp: knob 1 at compile time, everything else as shipped)
 #endif
 constexpr unsigned kSpinLimit = 4u << 20;      // global polls of ~0.1-3 us: >= 0.5 s
 constexpr unsigned kLdsSpinLimit = 1u << 26;   // LDS polls of ~50 ns
@@ -369,6 +374,30 @@ __device__ __forceinline__ unsigned l2_read_scalar(const unsigned* p)
     return r;
 }
 
+// s_waitcnt vmcnt(0), as the BUILTIN: the compiler's own wait-count bookkeeping sees it.  (Written in assembly it is
+// invisible: the compiler carries the round's sixteen Y stores as still pending into the next round and puts
+// s_waitcnt vmcnt(1) / vmcnt(0) in front of the first writes to their data registers -- which, in the hardware's count,
+// are the two LDS-DMA instructions just issued in assembly.)  gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt 6:4,
+// lgkmcnt 11:8.
+__device__ __forceinline__ void drain_vector_memory()
+{
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+}
+
+// A word of LDS, read in assembly: no compiler-placed s_waitcnt vmcnt(0) in front of it (an atomic load of LDS got one
+// while the builtin form of the LDS-DMA was in flight; none of these words is ever a DMA target).  The low half of a
+// generic pointer into LDS is the LDS address.
+__device__ __forceinline__ unsigned lds_peek(const unsigned* p)
+{
+    unsigned r;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                 : "=v"(r)
+                 : "v"(static_cast<unsigned>(reinterpret_cast<unsigned long long>(p)))
+                 : "memory");
+    return r;
+}
+
 // Barrier among the 8 waves of one role (no s_barrier: that one spans both roles).  `target` = 8 x the number of
 // this role's barriers so far.  LDS operations of one wave execute in order, so the arrival follows its writes.
 // (split form: role_arrive where the wave is done, role_wait where it needs the others -- nothing stalls in between)
@@ -380,9 +409,9 @@ __device__ __forceinline__ void role_arrive(FusedSync* sy, int role, int lane)
 __device__ __forceinline__ bool role_wait(FusedSync* sy, int role, unsigned target)
 {
     unsigned spins = 0;
-    while (__hip_atomic_load(&sy->bar[role], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+    while (lds_peek(&sy->bar[role]) < target) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > kLdsSpinLimit || __hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
+        if (++spins > kLdsSpinLimit || lds_peek(&sy->abort)) return false;
     }
     return true;
 }
@@ -391,31 +420,32 @@ __device__ __forceinline__ bool role_barrier(FusedSync* sy, int role, unsigned t
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(&sy->bar[role], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     unsigned spins = 0;
-    while (__hip_atomic_load(&sy->bar[role], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+    while (lds_peek(&sy->bar[role]) < target) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > kLdsSpinLimit || __hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
+        if (++spins > kLdsSpinLimit || lds_peek(&sy->abort)) return false;
     }
     return true;
 }
 
 // Wait until the team's counter reaches `target`: wave 0 of the role polls the L2 (one lane), everybody else
 // watches the value it publishes in LDS.
+// dma_pending (knob 1 = 6, measurement only): the wave has LDS-DMA in flight and keeps off the LDS until it has landed.
 __device__ __forceinline__ bool team_wait(FusedCtl* ctl, FusedSync* sy, const unsigned* counter, unsigned* seen, unsigned target,
-                                          bool poller, int lane)
+                                          bool poller, int lane, bool dma_pending = false)
 {
-    if (__hip_atomic_load(seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) return true;
+    if (!dma_pending && lds_peek(seen) >= target) return true;
     unsigned spins = 0;
-    if (poller || FKNOB(1)) {
+    if (poller && dma_pending) {
         for (;;) {
-            const unsigned v = FKNOB(0) == 4 ? __builtin_amdgcn_readfirstlane(l2_read(counter)) : l2_read_scalar(counter);
+            const unsigned v = l2_read_scalar(counter);
             if (v >= target) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_store(seen, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 return true;
             }
-            if (FKNOB(0) == 0 || FKNOB(0) == 4) __builtin_amdgcn_s_sleep(2);
-            else if (FKNOB(0) == 2) __builtin_amdgcn_s_sleep(8);
-            if (++spins > kSpinLimit || __hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ||
-                ((spins & 255u) == 0 && ctl_load(&ctl->abort[0]) != 0)) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > kSpinLimit || ((spins & 255u) == 0 && l2_read_scalar(&ctl->abort[0]) != 0)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) {
                     __hip_atomic_store(&ctl->abort[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&sy->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -424,9 +454,29 @@ __device__ __forceinline__ bool team_wait(FusedCtl* ctl, FusedSync* sy, const un
             }
         }
     }
-    while (__hip_atomic_load(seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+    if (dma_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (poller) {
+        for (;;) {
+            const unsigned v = FKNOB(0) == 4 ? __builtin_amdgcn_readfirstlane(l2_read(counter)) : l2_read_scalar(counter);
+            if (v >= target) {
+                if (lane == 0) __hip_atomic_store(seen, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return true;
+            }
+            if (FKNOB(0) == 0 || FKNOB(0) == 4) __builtin_amdgcn_s_sleep(2);
+            else if (FKNOB(0) == 2) __builtin_amdgcn_s_sleep(8);
+            if (++spins > kSpinLimit || lds_peek(&sy->abort) ||
+                ((spins & 255u) == 0 && l2_read_scalar(&ctl->abort[0]) != 0)) {
+                if (lane == 0) {
+                    __hip_atomic_store(&ctl->abort[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&sy->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                return false;
+            }
+        }
+    }
+    while (lds_peek(seen) < target) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > kLdsSpinLimit || __hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
+        if (++spins > kLdsSpinLimit || lds_peek(&sy->abort)) return false;
     }
     return true;
 }
@@ -435,6 +485,7 @@ __device__ __forceinline__ bool team_wait(FusedCtl* ctl, FusedSync* sy, const un
 // of a round to g_fused_prof (tools/gpu_fused_profile.py prints them); never in the shipped library.
 #ifdef RPF_FUSED_PROFILE
 __device__ unsigned long long g_fused_prof[16];
+__device__ unsigned long long g_fused_prof_wg[256][16];     // the same per workgroup (32 xcd + rank), last launch
 // absolute 100 MHz time stamps of the hand-offs, [workgroup = 32 xcd + rank][round < 64][event]: 0 producers arrived,
 // 1 consumers saw `produced`, 2 consumers arrived, 3 producers saw `consumed` (tools/gpu_fused_profile.py prints
 // where the signals spend their time)
@@ -445,13 +496,20 @@ struct FusedClock {
     unsigned long long last, sum[8];
     __device__ __forceinline__ void start() { for (int i = 0; i < 8; ++i) sum[i] = 0; last = wall_clock64(); }
     __device__ __forceinline__ void stamp(int i) { const unsigned long long now = wall_clock64(); sum[i] += now - last; last = now; }
-    __device__ __forceinline__ void publish(int base, bool who) { if (who) { for (int i = 0; i < 7; ++i) atomicAdd(&g_fused_prof[base + i], sum[i]); atomicAdd(&g_fused_prof[base + 7], 1ull); } }
+    __device__ __forceinline__ void publish(int base, bool who, int wg = -1)
+    {
+        if (who) {
+            for (int i = 0; i < 7; ++i) atomicAdd(&g_fused_prof[base + i], sum[i]);
+            atomicAdd(&g_fused_prof[base + 7], 1ull);
+            if (wg >= 0) for (int i = 0; i < 7; ++i) g_fused_prof_wg[wg][base + i] = sum[i];
+        }
+    }
 };
 #define FSTAMP(i) fclk.stamp(i)
 #else
 struct FusedClock {
     __device__ __forceinline__ void start() {}
-    __device__ __forceinline__ void publish(int, bool) {}
+    __device__ __forceinline__ void publish(int, bool, int = -1) {}
 };
 #define FSTAMP(i) ((void)0)
 #define FTRACE(ev) ((void)0)
@@ -478,7 +536,7 @@ constexpr int fused_lds_bytes()
 #ifndef RPF_FUSED_NBUF
 #define RPF_FUSED_NBUF 2
 #endif
-template <class S, bool WINDOW, bool DMA, int NBUF = RPF_FUSED_NBUF, bool NT = false>
+template <class S, bool WINDOW, bool DMA, int NBUF = RPF_FUSED_NBUF, int NT = 0>
 __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* __restrict__ stream, int nframes,
                                                                const cf* __restrict__ tw_n1,
                                                                const cf* __restrict__ tw_n2,
@@ -541,7 +599,10 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
     __syncthreads();                                 // the only workgroup-wide barrier before the output stage
     const int xcd = sy->team[0], rank = sy->team[1];
     if (!sy->team[2] || rank >= 32) return;
-    const int fsl = rank / TPF, tl = rank % TPF;            // frame slot of the round, tile of the frame
+    // (measurement knob 1, profile build: the tiles rotated by half a frame against the ranks -- does a slow workgroup
+    //  follow its tile or its CU?)
+    const int fsl = rank / TPF, tl = (rank % TPF + (FKNOB(1) == 1 ? TPF / 2 : 0)) % TPF;            // frame slot of the round, tile of the frame
+    const int YROT = FKNOB(1) == 2 ? 7 % TPF : 0;     // (knob 1 = 2: the tiles' places in Y rotated by 7 -- does the slow tile follow its address?)
     const int nrounds = (nframes + FR - 1) / FR;
     const int nj = xcd < nrounds ? (nrounds - xcd + 7) / 8 : 0;    // this team's rounds: xcd, xcd + 8, ...
     cf* const Yteam = Yall + static_cast<size_t>(xcd) * NBUF * FR * N + static_cast<size_t>(fsl) * N;     // + (j % NBUF) * FR * N
@@ -552,6 +613,45 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
     bool alive = true;
     FusedClock fclk;
 
+    // Raw rows of (frame f, tile tl) -> LDS in 16-byte pieces, asynchronously (LDS-DMA) when DMA: two instructions
+    // per wave and round.  (Dword pieces into padded rows -- conflict-free column reads -- took 72 LDS-DMA
+    // instructions per workgroup and round, ~1.8 us of the CU's memory pipeline, and every poll of a team counter
+    // queued behind them: the consumers saw `produced` 2.0 - 3.8 us late.  The 8-way bank conflicts of the unpadded
+    // rows cost the sixteen ds_read_u16 of a round ~0.06 us.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // m0 on the clobber list: meant
+    auto stage_rows = [&](int f) {
+        const uint8_t* const frame = stream + static_cast<size_t>(f) * (2 * N);
+        constexpr int PPR = ROWB / 16;                      // pieces per row
+        static_assert(N1 * PPR == 2 * kRoleThreads, "two pieces per producer thread");
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = i * kRoleThreads + rtid;
+            const uint8_t* src = frame + 2 * (static_cast<size_t>(N2) * (q / PPR) + COLS * tl) + 16 * (q % PPR);
+            if constexpr (DMA) {
+                // In assembly: the compiler's wait-count bookkeeping then knows nothing of the LDS-DMA and puts no
+                // s_waitcnt vmcnt(0) between here and the end of the round.  (Told of it -- the builtin -- it waits in
+                // front of the first LDS access it cannot prove disjoint from the DMA's target: right behind the
+                // issue, or in front of the next poll of an LDS flag, as its heuristics fall.)  The wait that counts is
+                // drain_vector_memory() at the end of the round.  No other instruction of this kernel uses m0.
+                const unsigned dst = __builtin_amdgcn_readfirstlane(
+                    static_cast<unsigned>(reinterpret_cast<unsigned long long>(raw + 16 * (i * kRoleThreads + rw * 64))));
+                if constexpr (NT) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" :: "v"(src), "s"(dst) : "memory", "m0");
+                else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory", "m0");
+            } else {
+                uint16_t h[8];                              // (any even stream address)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) h[k] = *reinterpret_cast<const uint16_t*>(src + 2 * k);
+                uint4 v;
+                v.x = h[0] | (static_cast<uint32_t>(h[1]) << 16);
+                v.y = h[2] | (static_cast<uint32_t>(h[3]) << 16);
+                v.z = h[4] | (static_cast<uint32_t>(h[5]) << 16);
+                v.w = h[6] | (static_cast<uint32_t>(h[7]) << 16);
+                *reinterpret_cast<uint4*>(raw + 16 * q) = v;
+            }
+        }
+    };
+#pragma clang diagnostic pop
     if (producer) {
         // ================================ producers: columns ====================================
         const int sub0 = lane / TA, t0 = lane % TA;
@@ -575,37 +675,9 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                 if constexpr (WINDOW) wsgn[g][a] = window[static_cast<size_t>(c) * N1 + t0 + TA * a] * ((c & 1) ? -1.0f : 1.0f);
         }
         exchange_sync<false>();              // (steptab rows are written and read by the same lane group)
-        // Raw rows of (frame f, tile tl) -> LDS in 16-byte pieces, asynchronously (LDS-DMA) when DMA: two instructions
-        // per wave and round.  (Dword pieces into padded rows -- conflict-free column reads -- took 72 LDS-DMA
-        // instructions per workgroup and round, ~1.8 us of the CU's memory pipeline, and every poll of a team counter
-        // queued behind them: the consumers saw `produced` 2.0 - 3.8 us late.  The 8-way bank conflicts of the unpadded
-        // rows cost the sixteen ds_read_u16 of a round ~0.06 us.)
-        auto stage_rows = [&](int f) {
-            const uint8_t* const frame = stream + static_cast<size_t>(f) * (2 * N);
-            constexpr int PPR = ROWB / 16;                      // pieces per row
-            static_assert(N1 * PPR == 2 * kRoleThreads, "two pieces per producer thread");
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int q = i * kRoleThreads + rtid;
-                const uint8_t* src = frame + 2 * (static_cast<size_t>(N2) * (q / PPR) + COLS * tl) + 16 * (q % PPR);
-                if constexpr (DMA) {
-                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(raw + 16 * (i * kRoleThreads + rw * 64)), 16, 0, 0);
-                } else {
-                    uint16_t h[8];                              // (any even stream address)
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) h[k] = *reinterpret_cast<const uint16_t*>(src + 2 * k);
-                    uint4 v;
-                    v.x = h[0] | (static_cast<uint32_t>(h[1]) << 16);
-                    v.y = h[2] | (static_cast<uint32_t>(h[3]) << 16);
-                    v.z = h[4] | (static_cast<uint32_t>(h[5]) << 16);
-                    v.w = h[6] | (static_cast<uint32_t>(h[7]) << 16);
-                    *reinterpret_cast<uint4*>(raw + 16 * q) = v;
-                }
-            }
-        };
         if (nj > 0 && xcd * FR + fsl < nframes) stage_rows(xcd * FR + fsl);
         unsigned nbar = 0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        drain_vector_memory();
         alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane);          // the first round's raw rows are in
         fclk.start();
 #pragma unroll 1
@@ -635,7 +707,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                 }
             }
             if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;
-            if (j + 1 < nj && f + 8 * FR < nframes) stage_rows(f + 8 * FR);
+            if (j + 1 < nj && f + 8 * FR < nframes && FKNOB(1) < 3) stage_rows(f + 8 * FR);     // (knob 1 = 3: no raw rows -- garbage in, timing only)
             FSTAMP(0);                       // samples in registers, next rows on their way
             // Both column groups are transformed BEFORE the team's one buffer is free (the consumers are still loading
             // the previous round out of it): the second group waits in this wave's slab in natural k1 order, the
@@ -669,9 +741,14 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                 }
             }
             FSTAMP(1);                       // both column groups transformed
+            // (knob 1 = 5: the next rows' LDS-DMA is issued here instead, under the wait for the buffer; 6: and the wave keeps
+            //  off the LDS until they have landed.  Both measured slower than the issue at the top of the round, 0.255 / 0.257
+            //  against 0.285 Tsample/s: profiles/r04_c4_fused.txt.)
+            if (FKNOB(1) >= 5 && j + 1 < nj && f + 8 * FR < nframes) stage_rows(f + 8 * FR);
+            if (FKNOB(1) == 6 && j < NBUF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // the team has finished reading round j - NBUF out of the buffer
             if (j >= NBUF && !(alive = team_wait(ctl, sy, &ctl->consumed[xcd][j % NBUF][0], &sy->seen[0][j % NBUF], 32u * (j / NBUF),
-                                                 rw == 0, lane))) break;
+                                                 rw == 0, lane, FKNOB(1) == 6))) break;
             FTRACE(3);
             FSTAMP(2);                       // wait: buffer free
             if (valid) {
@@ -690,14 +767,14 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                         cf4 v;
                         v.lo = slab[GA::slot(e)];
                         v.hi = slab[GA::slot(e + 1)];
-                        *reinterpret_cast<cf4*>(ycol + static_cast<size_t>(e / RT) * (N2 * RT) + e % RT) = v;
+                        *reinterpret_cast<cf4*>(ycol + static_cast<size_t>((e / RT + YROT) % TPF) * (N2 * RT) + e % RT) = v;
                     }
                     exchange_sync<false>();
                 }
             }
             // The round's rows of Y sit in the team's L2 once every producer wave's stores have drained (plain stores:
             // the lines stay there, dirty -- profiles/r04_l2_residency.txt); the next round's raw rows landed long ago.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            drain_vector_memory();
             FSTAMP(3);                       // stores issued and drained
             if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;
             if (rw == 0 && lane == 0)
@@ -705,7 +782,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
             FTRACE(0);
             FSTAMP(4);                       // arrived
         }
-        fclk.publish(0, rw == 0 && lane == 0);
+        fclk.publish(0, rw == 0 && lane == 0, 32 * xcd + rank);
     } else {
         // ================================ consumers: rows =======================================
         const int sub = lane / TB, t = lane % TB;
@@ -730,7 +807,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
             FTRACE(1);
             FSTAMP(0);                       // wait: round produced
             if (valid) {
-                const cf* const yt = Yteam + static_cast<size_t>(j % NBUF) * FR * N + static_cast<size_t>(tl) * (N2 * RT);
+                const cf* const yt = Yteam + static_cast<size_t>(j % NBUF) * FR * N + static_cast<size_t>((tl + YROT) % TPF) * (N2 * RT);
                 // sc1 loads: served by the L2, never by this CU's L1 (other CUs wrote these lines); 16 bytes per lane,
                 // all eight of a thread's loads in flight -- and the wait for them in the SAME asm statement: the
                 // compiler does not know that an asm load's destination is written when the data returns, and is free
@@ -740,7 +817,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                 const cf* src[PERB];
 #pragma unroll
                 for (int i = 0; i < PERB; ++i) src[i] = yt + 2 * (i * kRoleThreads + rtid);
-                if constexpr (NT) {
+                if constexpr (NT == 1) {
                     asm volatile(
                         "global_load_dwordx4 %0, %8, off sc1 nt\n\t"
                         "global_load_dwordx4 %1, %9, off sc1 nt\n\t"
@@ -806,7 +883,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
             }
             FSTAMP(3);                       // rows transformed
         }
-        fclk.publish(8, rw == 0 && lane == 0);
+        fclk.publish(8, rw == 0 && lane == 0, 32 * xcd + rank);
         // partial spectrum of (team, frame slot): the accumulators go through the tile area (the consumers' own: every
         // consumer wave has left its last round's column reads behind at that round's barrier) as [N2 k2][ROW_PITCH] doubles
         if (alive) {
@@ -847,6 +924,10 @@ __global__ void fused_poison_kernel(const FusedCtl* __restrict__ ctl, double* __
 extern "C" int rpf_debug_fused_trace(unsigned long long* out)      // 256 x 64 x 4 values
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(rpf::g_fused_trace), sizeof(unsigned long long) * 256 * 64 * 4) == hipSuccess ? 0 : 1;
+}
+extern "C" int rpf_debug_fused_profile_wg(unsigned long long* out)      // 256 x 16 values
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(rpf::g_fused_prof_wg), sizeof(unsigned long long) * 256 * 16) == hipSuccess ? 0 : 1;
 }
 extern "C" int rpf_debug_fused_knobs(const int* four)
 {
@@ -991,7 +1072,7 @@ struct SplitInfo {
     FusedFn fused[2][2];         // [window][dma]
     int fused_lds, fused_fr;     // LDS bytes; frames per team round
 #ifdef RPF_FUSED_PROFILE
-    FusedFn fused_ab[4];         // measurement only (RPF_FUSED_MODE=0..3, rectangular + LDS-DMA): NBUF 2/2/1/1, NT yes/no/no/yes
+    FusedFn fused_ab[4];         // measurement only (RPF_FUSED_MODE=0..3, rectangular + LDS-DMA): NBUF 2/2/1/2, NT both/none/none/raw rows only
 #endif
 };
 
@@ -1007,8 +1088,8 @@ SplitInfo make_split()
                       {fourstep_fused_kernel<S, true, false>, fourstep_fused_kernel<S, true, true>}},
                      fused_lds_bytes<S>(), 262144 / S::N,
 #ifdef RPF_FUSED_PROFILE
-                     {fourstep_fused_kernel<S, false, true, 2, true>, fourstep_fused_kernel<S, false, true, 2, false>,
-                      fourstep_fused_kernel<S, false, true, 1, false>, fourstep_fused_kernel<S, false, true, 1, true>}
+                     {fourstep_fused_kernel<S, false, true, 2, 1>, fourstep_fused_kernel<S, false, true, 2, 0>,
+                      fourstep_fused_kernel<S, false, true, 1, 0>, fourstep_fused_kernel<S, false, true, 2, 2>}
 #endif
     };
 }

@@ -9,7 +9,13 @@ import rtl_power_fftw_amd as rpf
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 dev = torch.device("cuda:0")
-d_in = rpf.synth.noise_tones_iq_torch(4, N * R, dev)
+d_in = (torch.from_numpy(rpf.synth.uniform_iq(4, N * R)).to(dev) if os.environ.get("PROFILE_STREAM") == "uniform"
+        else rpf.synth.noise_tones_iq_torch(4, N * R, dev))      # PROFILE_STREAM=uniform: uniformly random bytes instead of noise + tones
+SHIFT = int(os.environ.get("PROFILE_SHIFT", "0"))        # the stream this many bytes further into its allocation (multiple of 16)
+if SHIFT:
+    d_big = torch.empty(d_in.numel() + SHIFT, dtype=torch.uint8, device=dev)
+    d_big[SHIFT:] = d_in
+    d_in = d_big[SHIFT:]
 d_out = torch.zeros(N, dtype=torch.float64, device=dev)
 s = torch.cuda.current_stream().cuda_stream
 names = ["P samples -> registers, barrier, next rows' DMA issue", "P both column groups", "P wait: buffer free", "P stores + drain", "P role barrier + arrive", "-", "-",
@@ -61,3 +67,25 @@ for flags, label in ((rpf._lib.FLAG_FOURSTEP_FUSED, "fused"), (rpf._lib.FLAG_NO_
             print("   last consumer arrival -> first producer sees   %6.2f   -> last producer sees %6.2f" % (np.mean(ps[:, 1:].min(0) - ca[:, :-1].max(0)), np.mean(ps[:, 1:].max(0) - ca[:, :-1].max(0))))
             print("   producer sees -> producer arrives (mean CU)    %6.2f" % np.mean(pa[:, 1:] - ps[:, 1:]))
             print("   round period                                   %6.2f" % np.mean(np.diff(pa.max(0))))
+            # which round do the consumers work on while the producers arrive for round j?  (lag in rounds, from the stamps)
+            lag_c = np.mean(cs.mean(0) - pa.max(0))
+            print("   consumers see round j this long after its last producer arrival (mean CU) %6.2f" % lag_c)
+            print("   producers see `consumed` of round j - NBUF this long BEFORE/after they finish transforms: see 'P wait: buffer free'")
+            # per workgroup (rank = 32 / TPF frame slot x tile): how long each takes from seeing `produced` to arriving on
+            # `consumed` (tile load + barrier), from seeing `consumed` to arriving on `produced` (stores + drain + barrier),
+            # and how far behind the team's first it runs
+            print("   per rank: consumer sees->arrives | producer sees->arrives | consumer's lag behind the team's first to see")
+            for r in range(32):
+                print("    rank %2d: %6.2f | %6.2f | %6.2f" % (r, np.mean(ca[r] - cs[r]), np.mean(pa[r, 1:] - ps[r, 1:]), np.mean(cs[r] - cs.min(0))))
+            if hasattr(lib, "rpf_debug_fused_profile_wg"):
+                pw = np.zeros((256, 16), dtype=np.uint64)
+                lib.rpf_debug_fused_profile_wg(pw.ctypes.data_as(ctypes.c_void_p))
+                pw = pw.astype(np.float64).reshape(8, 32, 16) / rounds / 100.0      # us per round, [xcd][rank][segment]
+                print("   per rank of team 0, us per round: P top | P transforms | P wait | P stores+drain | P barrier || C wait | C tile load | C barrier | C transforms")
+                for r in range(32):
+                    print("    rank %2d: " % r + " ".join("%5.2f" % pw[0, r, i] for i in range(5)) + " || " + " ".join("%5.2f" % pw[0, r, 8 + i] for i in range(4)))
+            for team in range(8):
+                y = tr[team]
+                lagc = np.mean(y[:, 10:40, 1] - y[:, 10:40, 1].min(0), axis=1)
+                lagp = np.mean(y[:, 10:40, 0] - y[:, 10:40, 0].min(0), axis=1)
+                print("   team %d: consumers' lag by rank " % team + " ".join("%.0f" % v for v in lagc) + " | producers' arrival lag " + " ".join("%.0f" % v for v in lagp))
