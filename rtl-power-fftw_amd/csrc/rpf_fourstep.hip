@@ -652,6 +652,9 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
         }
     };
 #pragma clang diagnostic pop
+    // (knob 1 = 7 / 8, measurement: the consumer / producer waves at raised issue priority)
+    if (FKNOB(1) == 7 && !producer) __builtin_amdgcn_s_setprio(2);
+    if (FKNOB(1) == 8 && producer) __builtin_amdgcn_s_setprio(2);
     if (producer) {
         // ================================ producers: columns ====================================
         const int sub0 = lane / TA, t0 = lane % TA;
