@@ -389,8 +389,25 @@ void worker_main(rpf_engine* e)
         e->recycle_stop = false;
         e->recycler_error.clear();
     }
-    std::thread recycler(recycler_main, e);
+    std::thread recycler;
+    try {
+        recycler = std::thread(recycler_main, e);
+    } catch (const std::exception& ex) {
+        // no second thread to be had: the acquisition fails (rpf_finish says why) and this thread keeps the hand-off
+        // protocol alive by returning every buffer itself
+        if (ok()) {
+            e->worker_rc = RPF_ERR_HARDWARE;
+            e->worker_error = std::string("cannot start the buffer recycler thread: ") + ex.what();
+        }
+    }
     auto hand_back = [&](HostBuffer* b, hipEvent_t copied) {
+        if (!recycler.joinable()) {
+            if (copied) (void)hipEventSynchronize(copied);
+            std::lock_guard<std::mutex> status(e->status_mutex);
+            e->empty_buffers.push_back(b);
+            e->status_change.notify_all();
+            return;
+        }
         std::lock_guard<std::mutex> lk(e->recycle_mutex);
         e->recycle_queue.emplace_back(copied, b);
         e->recycle_cv.notify_one();
@@ -498,7 +515,7 @@ void worker_main(rpf_engine* e)
         e->recycle_stop = true;
         e->recycle_cv.notify_one();
     }
-    recycler.join();             // every buffer is back in empty_buffers
+    if (recycler.joinable()) recycler.join();             // every buffer is back in empty_buffers
     if (ok() && !e->recycler_error.empty()) {
         e->worker_rc = RPF_ERR_HARDWARE;
         e->worker_error = e->recycler_error;
@@ -849,7 +866,11 @@ int rpf_begin(rpf_engine* e, int64_t repeats)
     e->worker_rc = RPF_OK;
     e->worker_error.clear();
     // acquisition.cxx:256
-    e->worker = std::thread(worker_main, e);
+    try {
+        e->worker = std::thread(worker_main, e);
+    } catch (const std::exception& ex) {      // (no exception crosses the C boundary)
+        return fail(e, RPF_ERR_HARDWARE, std::string("rpf_begin: cannot start the consumer thread: ") + ex.what());
+    }
     e->worker_running = true;
     return RPF_OK;
 }
