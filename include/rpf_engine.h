@@ -59,7 +59,8 @@ typedef struct rpf_config {
 /* Sizes 16384..262144 (the four-step sizes): the fused persistent kernel -- ONE launch per acquisition, the
  * intermediate is handed from the column transforms to the row transforms inside each XCD's L2 instead of crossing
  * the fabric between two kernels.  It is what these sizes run by default on a 256-CU part (65536 ... 262144; 16384 and
- * 32768 default to the LDS mixed-radix kernels, so asking for it here is also asking for the four-step path) whenever
+ * 32768 default to the LDS mixed-radix kernels -- windowed runs of 32768 excepted, which are faster here -- so asking for
+ * it is also asking for the four-step path) whenever
  * its eight workgroup teams assemble at rpf_engine_create; otherwise the engine keeps the two-kernel path.  A launch
  * whose teams do not assemble later (a CU held by someone else's kernel for ~0.5 s) NaN-fills the spectrum and
  * rpf_finish reports RPF_ERR_HARDWARE: loud, never wrong.   */

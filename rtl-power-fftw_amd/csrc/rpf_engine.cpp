@@ -590,7 +590,12 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
                     "Number of bins must be a positive even number.");
     const int variant = static_cast<int>((cfg->flags >> 8) & 0xffu);
     // (asking for the fused four-step kernel is asking for the four-step path)
-    const bool mixed = rpf::mixed_supported(cfg->N, variant) &&
+    // 32768 is served twice, by the split form 2 x 16384 and by the four-step kernels.  Plain runs are faster on the
+    // former (0.37 against 0.22 Tsample/s); WINDOWED runs are not: the 16384-point plan has no registers left for the
+    // window values next to its two-deep section pipeline (0.175, it was 0.27 before round 3's section sums), the
+    // four-step kernels multiply them in as they unpack (0.21 - 0.22).  profiles/r04_sizes.txt.
+    const bool windowed_32768 = cfg->N == 32768 && cfg->window != nullptr && variant == 0;
+    const bool mixed = rpf::mixed_supported(cfg->N, variant) && !windowed_32768 &&
                        !(cfg->flags & (RPF_FLAG_NO_MIXED_RADIX | RPF_FLAG_FOURSTEP_FUSED));
     const bool fourstep = !mixed && rpf::fourstep_supported(cfg->N) && variant == 0;
     const bool bluestein = !mixed && rpf::bluestein_supported(cfg->N) && variant == 0;

@@ -158,7 +158,8 @@ def test_split_mixed_radix_sizes_match_oracle(N, torch_dev):
     """N = P x M (P = 2 ... 5, M <= 16384 one of the planned lengths): the split form of the mixed-radix kernel
     (one workgroup per residue of the spectrum, rpf_mixed.hip) against the float32 oracle, float64 truth and the
     kernels it replaces by default (large Bluestein; the four-step pair for 32768); frame counts that leave some
-    groups of workgroups idle or the grid off a multiple of 8 P (the other workgroup -> residue mapping)."""
+    groups of workgroups idle or the grid off a multiple of 8 P (the other workgroup -> residue mapping).
+    (Windowed runs of 32768 take the four-step path by default since round 4: both engines are the same kernel there.)"""
     R = 11
     stream = rpf.synth.uniform_iq(77 + N % 101, N * R + N // 2)
     for windowed in (False, True):
@@ -255,7 +256,8 @@ def test_four_step_sizes_match_oracle(N, fused, torch_dev):
     kernel (the default of these sizes) and on the two-kernel path it falls back to."""
     R = 20 if N < 262144 else 12
     stream = rpf.synth.uniform_iq(44 + N % 97, N * R + 1000)
-    # (16384 and 32768 also fit the LDS mixed-radix kernels, which is what runs by default: test_mixed_radix_...)
+    # (16384 and 32768 also fit the LDS mixed-radix kernels, which is what runs by default -- windowed 32768 excepted:
+    #  test_split_mixed_radix_...)
     path = rpf._lib.FLAG_NO_MIXED_RADIX | (0 if fused else rpf._lib.FLAG_NO_FOURSTEP_FUSED)
     for windowed in (False, True):
         w = rpf.synth.hann_window(N) + np.float32(0.25) if windowed else None
