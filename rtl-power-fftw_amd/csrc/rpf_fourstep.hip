@@ -668,7 +668,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
         float wsgn[WINDOW ? GROUPS : 1][P];
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
-            const int cl = (rw * GROUPS + g) * S::SUBA + sub0;
+            const int cl = (rw * S::SUBA + sub0) * GROUPS + g;     // a lane's two columns are neighbours: one dword of a raw row
             const int c = COLS * tl + cl;
             ustep[g] = twN[static_cast<size_t>(c) * N1 + t0];
             if (t0 < P) steptab[cl * P + t0] = twN[static_cast<size_t>(c) * N1 + TA * t0];
@@ -696,18 +696,16 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
             cf* const slab = slabsA + rw * S::SLAB_A + sub * GA::LDS_CPX;
             // Both column groups' samples go to registers first: the raw area is then free for the next round's rows,
             // whose LDS-DMA runs under this round's arithmetic.
-            uint32_t iq[GROUPS][P / 2];          // two samples per register: I0 Q0 I1 Q1
+            // One dword of a row holds the lane's sample of BOTH groups (columns 2 k, 2 k + 1: I0 Q0 I1 Q1): eight LDS reads
+            // per thread and round instead of sixteen, and these are the kernel's worst -- consecutive lanes read
+            // consecutive unpadded rows, 32 ... 128 bytes apart, 16 lanes to a bank (SQ_LDS_BANK_CONFLICT: a third of the
+            // kernel's LDS cycles are conflicts, half of them here; profiles/r04_c4_fused.txt 6.).
+            uint32_t iq[P];
+            static_assert(GROUPS == 2, "a dword of raw bytes = two columns");
             if (valid) {
+                const int cl0 = (rw * S::SUBA + sub) * GROUPS;
 #pragma unroll
-                for (int g = 0; g < GROUPS; ++g) {
-                    const int cl = (rw * GROUPS + g) * S::SUBA + sub;
-#pragma unroll
-                    for (int a = 0; a < P; a += 2) {
-                        const uint32_t lo = *reinterpret_cast<const uint16_t*>(raw + (t + TA * a) * ROWB + 2 * cl);
-                        const uint32_t hi = *reinterpret_cast<const uint16_t*>(raw + (t + TA * (a + 1)) * ROWB + 2 * cl);
-                        iq[g][a / 2] = lo | (hi << 16);
-                    }
-                }
+                for (int a = 0; a < P; ++a) iq[a] = *reinterpret_cast<const uint32_t*>(raw + (t + TA * a) * ROWB + 2 * cl0);
             }
             if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;
             if (j + 1 < nj && f + 8 * FR < nframes && FKNOB(1) < 3) stage_rows(f + 8 * FR);     // (knob 1 = 3: no raw rows -- garbage in, timing only)
@@ -718,7 +716,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
             cf y0[P];
 #pragma unroll
             for (int g = 0; g < GROUPS; ++g) {
-                const int cl = (rw * GROUPS + g) * S::SUBA + sub;       // this lane group's column inside the tile
+                const int cl = (rw * S::SUBA + sub) * GROUPS + g;       // this lane group's column inside the tile
                 const int c = COLS * tl + cl;                           // n2
                 if (valid) {
                     const float sgn = (c & 1) ? -1.0f : 1.0f;           // (-1)^n, n = N2 n1 + n2
@@ -726,7 +724,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                     cf x[P];
 #pragma unroll
                     for (int a = 0; a < P; ++a) {
-                        const cf v = (a & 1) ? iq_pair_plus_2p23<1>(iq[g][a / 2]) : iq_pair_plus_2p23<0>(iq[g][a / 2]);
+                        const cf v = g ? iq_pair_plus_2p23<1>(iq[a]) : iq_pair_plus_2p23<0>(iq[a]);
                         if constexpr (WINDOW) x[a] = (v - (kTwo23 + 127.0f)) * wsgn[g][a];
                         else x[a] = v * sgn + off;
                     }
@@ -757,7 +755,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
             if (valid) {
 #pragma unroll
                 for (int g = GROUPS - 1; g >= 0; --g) {
-                    const int c = COLS * tl + (rw * GROUPS + g) * S::SUBA + sub;
+                    const int c = COLS * tl + (rw * S::SUBA + sub) * GROUPS + g;
                     if (g == 0) {
 #pragma unroll
                         for (int a = 0; a < P; ++a) slab[GA::slot(bin_of<GA>(t, a))] = y0[a];
