@@ -553,6 +553,10 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
     constexpr int FR = 32 / TPF;                    // frames per round
     constexpr int COLS = 16 * S::SUBA;              // columns per workgroup and round
     constexpr int ROWB = 2 * COLS;                  // bytes per staged raw row (32 ... 128), unpadded: 16-byte LDS-DMA pieces
+    constexpr int RPB = 64 / (ROWB / 16);           // rows per 1 KB block of the staged rows (one LDS-DMA instruction)
+    // the blocks' pieces piece-major (stage_rows) where a row is 64 or 128 bytes: measured + 4 - 5 % at 16384 ... 65536,
+    // + 0.7 % at 131072 and - 0.5 % on C4, whose 32-byte rows stay row-major (profiles/r04_c4_fused.txt 6.)
+    constexpr bool PIECE_MAJOR = ROWB > 32;
     constexpr int GROUPS = 2;                       // column / row groups per wave: 16 groups over 8 waves
     constexpr int RT = S::ROW_TILE, HALF = RT / 2;
     static_assert(TPF >= 1 && TPF <= 32 && N2 / COLS == TPF && N1 / RT == TPF, "tile counts");
@@ -626,8 +630,16 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
         static_assert(N1 * PPR == 2 * kRoleThreads, "two pieces per producer thread");
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            // PIECE_MAJOR: LDS piece q = 64 b + l <- row RPB b + l % RPB, piece l / RPB of the row (RPB = 64 / PPR rows per
+            // LDS-DMA instruction): the same piece of consecutive rows sits 16 bytes apart, and the 32 lanes that read one
+            // dword of 32 consecutive rows spread over 8 banks (4-way) -- row-major they meet in 2 or 1 of them (16-,
+            // 32-way) at 64 and 128 bytes per row.  At 32 bytes per row (8-way) the doubled memory requests of the
+            // scattered pieces cost what the banks give back.
             const int q = i * kRoleThreads + rtid;
-            const uint8_t* src = frame + 2 * (static_cast<size_t>(N2) * (q / PPR) + COLS * tl) + 16 * (q % PPR);
+            static_assert(RPB == 64 / PPR, "");
+            const int row = PIECE_MAJOR ? RPB * (q / 64) + (q % 64) % RPB : q / PPR;
+            const int piece = PIECE_MAJOR ? (q % 64) / RPB : q % PPR;
+            const uint8_t* src = frame + 2 * (static_cast<size_t>(N2) * row + COLS * tl) + 16 * piece;
             if constexpr (DMA) {
                 // In assembly: the compiler's wait-count bookkeeping then knows nothing of the LDS-DMA and puts no
                 // s_waitcnt vmcnt(0) between here and the end of the round.  (Told of it -- the builtin -- it waits in
@@ -705,7 +717,11 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
             if (valid) {
                 const int cl0 = (rw * S::SUBA + sub) * GROUPS;
 #pragma unroll
-                for (int a = 0; a < P; ++a) iq[a] = *reinterpret_cast<const uint32_t*>(raw + (t + TA * a) * ROWB + 2 * cl0);
+                for (int a = 0; a < P; ++a) {
+                    const int row = t + TA * a, byte = 2 * cl0;                 // (stage_rows' layout)
+                    iq[a] = *reinterpret_cast<const uint32_t*>(
+                        PIECE_MAJOR ? raw + 1024 * (row / RPB) + 16 * ((byte / 16) * RPB + row % RPB) + byte % 16 : raw + row * ROWB + byte);
+                }
             }
             if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;
             if (j + 1 < nj && f + 8 * FR < nframes && FKNOB(1) < 3) stage_rows(f + 8 * FR);     // (knob 1 = 3: no raw rows -- garbage in, timing only)
