@@ -35,6 +35,7 @@
 #include <mutex>
 #include <cstdlib>
 
+#include "fused_layout.h"
 #include "rpf_device_common.h"
 #include "rpf_kernels.h"
 
@@ -553,10 +554,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
     constexpr int FR = 32 / TPF;                    // frames per round
     constexpr int COLS = 16 * S::SUBA;              // columns per workgroup and round
     constexpr int ROWB = 2 * COLS;                  // bytes per staged raw row (32 ... 128), unpadded: 16-byte LDS-DMA pieces
-    constexpr int RPB = 64 / (ROWB / 16);           // rows per 1 KB block of the staged rows (one LDS-DMA instruction)
-    // the blocks' pieces piece-major (stage_rows) where a row is 64 or 128 bytes: measured + 4 - 5 % at 16384 ... 65536,
-    // + 0.7 % at 131072 and - 0.5 % on C4, whose 32-byte rows stay row-major (profiles/r04_c4_fused.txt 6.)
-    constexpr bool PIECE_MAJOR = ROWB > 32;
+    using Raw = RawStage<ROWB>;                     // where a row's bytes sit in LDS (fused_layout.h: piece-major at 64 / 128 bytes per row)
     constexpr int GROUPS = 2;                       // column / row groups per wave: 16 groups over 8 waves
     constexpr int RT = S::ROW_TILE, HALF = RT / 2;
     static_assert(TPF >= 1 && TPF <= 32 && N2 / COLS == TPF && N1 / RT == TPF, "tile counts");
@@ -630,15 +628,9 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
         static_assert(N1 * PPR == 2 * kRoleThreads, "two pieces per producer thread");
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            // PIECE_MAJOR: LDS piece q = 64 b + l <- row RPB b + l % RPB, piece l / RPB of the row (RPB = 64 / PPR rows per
-            // LDS-DMA instruction): the same piece of consecutive rows sits 16 bytes apart, and the 32 lanes that read one
-            // dword of 32 consecutive rows spread over 8 banks (4-way) -- row-major they meet in 2 or 1 of them (16-,
-            // 32-way) at 64 and 128 bytes per row.  At 32 bytes per row (8-way) the doubled memory requests of the
-            // scattered pieces cost what the banks give back.
-            const int q = i * kRoleThreads + rtid;
-            static_assert(RPB == 64 / PPR, "");
-            const int row = PIECE_MAJOR ? RPB * (q / 64) + (q % 64) % RPB : q / PPR;
-            const int piece = PIECE_MAJOR ? (q % 64) / RPB : q % PPR;
+            const int q = i * kRoleThreads + rtid;              // LDS piece q <- (row, piece of the row): fused_layout.h
+            static_assert(Raw::PPR == PPR, "");
+            const int row = Raw::row_of(q), piece = Raw::piece_of(q);
             const uint8_t* src = frame + 2 * (static_cast<size_t>(N2) * row + COLS * tl) + 16 * piece;
             if constexpr (DMA) {
                 // In assembly: the compiler's wait-count bookkeeping then knows nothing of the LDS-DMA and puts no
@@ -719,8 +711,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
 #pragma unroll
                 for (int a = 0; a < P; ++a) {
                     const int row = t + TA * a, byte = 2 * cl0;                 // (stage_rows' layout)
-                    iq[a] = *reinterpret_cast<const uint32_t*>(
-                        PIECE_MAJOR ? raw + 1024 * (row / RPB) + 16 * ((byte / 16) * RPB + row % RPB) + byte % 16 : raw + row * ROWB + byte);
+                    iq[a] = *reinterpret_cast<const uint32_t*>(raw + Raw::offset(row, byte));
                 }
             }
             if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;

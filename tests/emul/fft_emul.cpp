@@ -13,6 +13,7 @@
 
 #include "../../rtl-power-fftw_amd/csrc/bluestein_tables.h"
 #include "../../rtl-power-fftw_amd/csrc/fft_core.h"
+#include "../../rtl-power-fftw_amd/csrc/fused_layout.h"
 #include "../../rtl-power-fftw_amd/csrc/mixed_core.h"
 
 namespace {
@@ -543,6 +544,47 @@ extern "C" int rpf_emul_fused_bin_split(int n1)
         case 128: return bin_split_violations<rpf::Geom<128, 8>>();
         case 256: return bin_split_violations<rpf::Geom<256, 8>>();
         case 512: return bin_split_violations<rpf::Geom<512, 8>>();
+        default: return -1;
+    }
+}
+
+// The fused four-step kernel's raw-row staging (fused_layout.h): every LDS piece q of a tile of `rows` rows of `rowb`
+// bytes holds a (row, piece) nobody else holds, and the reader's offset of every byte of that piece is where the
+// writer's lane put it (16 q + byte % 16).  Returns the number of violations, -1 for a row length there is no kernel for.
+template <int ROWB>
+static int raw_stage_violations(int rows)
+{
+    using R = rpf::RawStage<ROWB>;
+    const int pieces = rows * R::PPR;
+    if (pieces % 64 != 0) return -1;
+    std::vector<int> seen(pieces, 0);
+    int bad = 0;
+    for (int q = 0; q < pieces; ++q) {
+        const int row = R::row_of(q), piece = R::piece_of(q);
+        if (row < 0 || row >= rows || piece < 0 || piece >= R::PPR) { ++bad; continue; }
+        ++seen[row * R::PPR + piece];
+        for (int b = 0; b < 16; ++b)
+            if (R::offset(row, 16 * piece + b) != 16 * q + b) ++bad;
+    }
+    for (int v : seen) bad += v != 1;
+    return bad;
+}
+extern "C" int rpf_emul_fused_raw_stage(int rowb, int rows)
+{
+    switch (rowb) {
+        case 32: return raw_stage_violations<32>(rows);
+        case 64: return raw_stage_violations<64>(rows);
+        case 128: return raw_stage_violations<128>(rows);
+        default: return -1;
+    }
+}
+// bank (of 32, ds_read_b32) of the dword the lane of row `row` reads at byte `byte` of its row
+extern "C" int rpf_emul_fused_raw_bank(int rowb, int row, int byte)
+{
+    switch (rowb) {
+        case 32: return (rpf::RawStage<32>::offset(row, byte) / 4) % 32;
+        case 64: return (rpf::RawStage<64>::offset(row, byte) / 4) % 32;
+        case 128: return (rpf::RawStage<128>::offset(row, byte) / 4) % 32;
         default: return -1;
     }
 }

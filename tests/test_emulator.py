@@ -128,3 +128,21 @@ def test_fused_four_step_twiddle_factorisation_holds(n1):
     lib.rpf_emul_fused_bin_split.argtypes = [ctypes.c_int]
     assert lib.rpf_emul_fused_bin_split(n1) == 0
     assert lib.rpf_emul_fused_bin_split(64) == -1
+
+
+@pytest.mark.parametrize("rowb,rows", [(32, 512), (64, 256), (128, 128)])
+def test_fused_kernel_raw_row_staging_maps_agree(rowb, rows):
+    """csrc/fused_layout.h, the fused four-step kernel's tile of raw rows in LDS: the writer's map (which row and
+    piece LDS-DMA lane q fetches) and the reader's (where byte b of row r is) are one bijection, for the three row
+    lengths the kernel has (32 bytes x 512 rows ... 128 bytes x 128 rows); and the bank arithmetic behind the
+    piece-major choice: the 32 lanes of a ds_read_b32 group read one dword of 32 consecutive rows -- 8 banks piece-major,
+    no more than 4 row-major."""
+    import ctypes
+    from helpers import emul_lib
+    lib = emul_lib()
+    lib.rpf_emul_fused_raw_stage.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.rpf_emul_fused_raw_bank.argtypes = [ctypes.c_int] * 3
+    assert lib.rpf_emul_fused_raw_stage(rowb, rows) == 0
+    assert lib.rpf_emul_fused_raw_stage(48, rows) == -1
+    banks = {lib.rpf_emul_fused_raw_bank(rowb, row, 4) for row in range(32)}
+    assert len(banks) == (8 if rowb > 32 else 4)
