@@ -65,3 +65,24 @@ def test_no_tool_knows_the_held_out_streams():
         assert "test_gpu_heldout" not in body and "held_out_seeds" not in body and "HELD_OUT_KEY" not in body, path
     alt = open(os.path.join(root, "tools", "gpu_heldout_alternatives.py")).read()
     assert "pick" not in alt.lower().replace("picks nothing", "") and "mixed_plans" not in alt
+
+
+def test_lds_bank_model_of_the_fused_kernel():
+    """tools/lds_bank_model.py: the numbers profiles/r04_c4_fused.txt 6. quotes, and the model's own index maps --
+    Geom.bin_of is a bijection with the additive split the fused kernel's twiddle factorisation needs, the dropped
+    staging swizzles are permutations that keep a pair of bins adjacent."""
+    import lds_bank_model as m
+    for N in (512, 256, 128):
+        g = m.Geom(N)
+        bins = sorted(g.bin_of(t, a) for t in range(g.T) for a in range(g.P))
+        assert bins == list(range(N))
+        assert all(g.bin_of(t, a) == g.bin_of(t, 0) + g.bin_of(0, a) for t in range(g.T) for a in range(g.P))
+        for J in range(1, g.NPASS + 1):
+            assert sorted(g.elem(J, t, a) for t in range(g.T) for a in range(g.P)) == list(range(N))
+        assert m.exchange(N) == (128, 96)                               # first-pass stores take twice their cycles
+        assert m.staging(N) == (64, 32, 64, 32)                         # both directions twice
+        sw = m.SWIZZLE[N]
+        assert sorted(sw(k) for k in range(N)) == list(range(N))
+        assert m.staging(N, sw, N, wide=True) == (32, 32, 16, 16)       # conflict-free -- and measured worth nothing
+    assert [m.raw_rows(b, False)[0] for b in (32, 64, 128)] == [16, 32, 64]
+    assert [m.raw_rows(b, True)[0] for b in (32, 64, 128)] == [8, 8, 8]
