@@ -26,6 +26,16 @@ steps, then EXACTLY K steps between barrier + synchronize; when one such region 
 than 0.5 s it is repeated and the MEDIAN region is reported (regions listed in
 "timing"), so a 20-step run reports what a 2000-step run reports.
 
+Ranks: `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N
+ranks itself (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same
+arguments>`, one rank per device) and passes rank 0's line through; under torchrun (the driver's
+multi-GPU form) the environment's ranks are used as they are.  Fewer devices than ranks is an
+error (exit code 2), never a silent one-GPU measurement -- unless `--dist-backend gloo
+--share-device` asks for the REHEARSAL: every rank on device 0, the per-scan reduce staged through
+the host (sharding.ScanRing, host_staged), so that launcher, shards, ring reuse, per-rank
+reporting and the fixture check all run on the real kernels of a one-GPU box; its `value` is N
+ranks time-slicing one GPU and says nothing about scaling.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -242,53 +252,151 @@ def secondary_limits(N, frames_per_launch, kernel_s):
     return out
 
 
-def main():
-    # stdout carries exactly ONE line, the JSON: whatever libraries print there (RCCL's version
-    # banner, for one) goes to stderr instead
-    json_out = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
+def build_parser():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks of the job, one per device; > 1 without WORLD_SIZE in the environment: bench.py "
+                         "starts them itself under torch.distributed.run")
     ap.add_argument("--steps", type=int, default=None, help="default: 2000 (C2/C3), 200 (C5), 100 (C4)")
     ap.add_argument("--warmup", type=int, default=None, help="default: steps / 20")
     ap.add_argument("--replay-buffers", type=int, default=0, help="0 = enough to exceed the Infinity Cache")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
-                    help="initialise torch.distributed (RCCL) and run the reduce even with one rank")
+                    help="initialise torch.distributed and run the reduce even with one rank")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl = RCCL over xGMI (the product's exchange); gloo = the reduce staged through the host "
+                         "(rehearsal on boxes with fewer GPUs than ranks)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="(rehearsal, needs --dist-backend gloo) every rank uses device 0")
+    ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (0 = a free one)")
     ap.add_argument("--workload", choices=["auto", "C2", "C3", "C4", "C5"], default="auto")
     ap.add_argument("--engine-flags", type=int, default=0,
                     help="RPF_FLAG_* bits for the engine (A/B only, e.g. 8 = C4 on the two-kernel four-step path)")
     ap.add_argument("--shard-as", type=int, default=0,
-                    help="(diagnostic) C5: process only the shard rank 0 of a job of this many ranks would own -- "
-                         "shows whether the per-step host work keeps up with an 8-GPU step on one GPU; the line's value is then meaningless")
+                    help="(diagnostic) C5: process only the shard rank 0 of a job of this many ranks (2, 4, 8) would own "
+                         "-- the per-rank step time of that job on one GPU's clock, an upper bound on its speed-up; "
+                         "the line's value is then meaningless")
+    ap.add_argument("--scans-per-reduce", type=int, default=4,
+                    help="C5: scans whose spectra travel in ONE reduce (fewer, larger collectives: the 256 KB of one scan are "
+                         "latency-bound; 1 = a reduce per scan)")
     ap.add_argument("--event-every", type=int, default=8,
                     help="bracket the fused kernel with HIP events on every k-th timed step")
-    args = ap.parse_args()
+    return ap
+
+
+class LaunchError(Exception):
+    """The requested ranks cannot be started as asked (exit code 2)."""
+
+
+def check_rank_request(args, world, device_count):
+    """Ranks against devices: one rank per device, or the explicit rehearsal."""
+    if args.share_device and args.dist_backend != "gloo":
+        raise LaunchError("--share-device is the one-GPU rehearsal and needs --dist-backend gloo "
+                          "(RCCL cannot put two ranks on one device)")
+    if world > 1 and not args.share_device and device_count < world:
+        raise LaunchError("%d ranks asked for, %d HIP device(s) visible: refusing to measure fewer GPUs than "
+                          "the line would claim (rehearsal on one GPU: --dist-backend gloo --share-device)"
+                          % (world, device_count))
+    if device_count < 1:
+        raise LaunchError("no HIP device visible")
+
+
+def plan_launch(args, argv, environ, device_count, port=None, python=None, script=None):
+    """None: run in this process (one rank, or ranks already made by torchrun: WORLD_SIZE is set).
+    Otherwise the command that starts --gpus ranks of this script with the same arguments."""
+    if "WORLD_SIZE" in environ or args.gpus <= 1:
+        return None
+    check_rank_request(args, args.gpus, device_count)
+    if port is None:
+        port = args.master_port
+    if not port:
+        import socket
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(cmd, json_out):
+    """Run the ranks; rank 0's JSON line is the only thing that reaches stdout."""
+    import subprocess
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    lines = 0
+    try:
+        for line in proc.stdout:
+            if line.startswith('{"metric"') and lines == 0:
+                json_out.write(line if line.endswith("\n") else line + "\n")
+                json_out.flush()
+                lines += 1
+            else:
+                sys.stderr.write(line)
+        rc = proc.wait()
+    except BaseException:
+        proc.kill()
+        raise
+    if rc == 0 and lines != 1:
+        print("bench.py: the ranks exited 0 without printing a line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def main():
+    # stdout carries exactly ONE line, the JSON: whatever libraries print there (RCCL's version
+    # banner, for one) goes to stderr instead
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    args = build_parser().parse_args()
 
     import torch
     import torch.distributed as dist
+
+    try:
+        cmd = plan_launch(args, sys.argv[1:], os.environ, torch.cuda.device_count())
+    except LaunchError as exc:
+        print("bench.py: %s" % exc, file=sys.stderr)
+        sys.exit(2)
+    if cmd is not None:
+        sys.exit(self_launch(cmd, json_out))
     import rtl_power_fftw_amd as rpf
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
+    try:
+        check_rank_request(args, world, torch.cuda.device_count())
+    except LaunchError as exc:
+        if rank == 0:
+            print("bench.py: %s" % exc, file=sys.stderr)
+        sys.exit(2)
     use_dist = world > 1 or args.force_dist
+    gloo = args.dist_backend == "gloo"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if gloo:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node; the container's hostname may not resolve
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        print("warning: --gpus %d but WORLD_SIZE %d: the line reports the %d rank(s) that ran"
+              % (args.gpus, world, world), file=sys.stderr)
     dev = torch.device("cuda", local_rank if use_dist else 0)
     torch.cuda.set_device(dev)
+    ctrl_dev = torch.device("cpu") if gloo else dev       # where the timing/flag all-reduces live
 
     name = args.workload
+    selected = "explicit (--workload %s)" % name
     if name == "auto":
+        # BASELINE.json: the metric is quoted on config 2 (one GPU); config 5, the sharded scan, is the multi-GPU one
         name = "C2" if world == 1 else "C5"
+        selected = "auto: C2 (weak scaling) with one rank, C5 (strong scaling) with several -- this run: %s" % name
     wl = WORKLOADS[name]
     N, R = wl["N"], wl["R"]
     strong = name == "C5"
@@ -323,22 +431,21 @@ def main():
     # Exchange: one block = the `hops` spectra of a scan (C5) or of `hops`=8 consecutive
     # acquisitions (C2-C4), reduced onto rank 0 with ONE async RCCL reduce -- fewer, larger collectives --
     # on a ring of blocks so that it overlaps the following steps' kernels.
-    rows = hops if strong else 8
+    # C5: `--scans-per-reduce` consecutive scans share a block (the reduce of 256 KB is latency-bound: measured 17 us
+    # per scan at one per scan against a 33 us per-rank step at 8 ranks).
+    per_block = max(1, args.scans_per_reduce) if strong else 8       # steps whose spectra share a block
+    rows = hops * per_block if strong else per_block
     nring = 4
     # (strong scaling: rank 0 owns only some rows of a block and must clear the others before reuse;
     # weak scaling: every rank rewrites every row, nothing to clear)
-    ring = rpf.sharding.ScanRing(rows, N, dev, nring=nring, dst=0, enabled=use_dist, clear_on_reuse=strong)
+    ring = rpf.sharding.ScanRing(rows, N, dev, nring=nring, dst=0, enabled=use_dist, clear_on_reuse=strong,
+                                 host_staged=gloo)
     d_pwr = ring.blocks
     s = torch.cuda.current_stream().cuda_stream
 
     def step(i, ev=None):
-        if strong:
-            blk = i % nring
-            new_block, last_of_block = True, True
-        else:
-            blk, row = (i // rows) % nring, i % rows
-            new_block, last_of_block = row == 0, row == rows - 1
-        if new_block:
+        blk, sub = (i // per_block) % nring, i % per_block
+        if sub == 0:
             ring.begin(blk)
         streams = bufs[i % nb]
         if strong:
@@ -350,24 +457,24 @@ def main():
                                  [c for _, _, c in mine], s)
             if ev is not None:
                 ev[1].record()
-            ds.device_reduce(d_pwr[blk][mine[0][0]].data_ptr(), s)
+            ds.device_reduce(d_pwr[blk][sub * hops + mine[0][0]].data_ptr(), s)
         else:
             for k, (hop, first, count) in enumerate(mine):
-                out_row = d_pwr[blk][row]
+                out_row = d_pwr[blk][sub]
                 if ev is not None and k == 0:
                     ev[0].record()
                 ds.device_fused(streams[k].data_ptr(), 2 * N * count, count, s)
                 if ev is not None and k == 0:
                     ev[1].record()
                 ds.device_reduce(out_row.data_ptr(), s)
-        if last_of_block:
+        if sub == per_block - 1:
             ring.submit(blk)
         return blk
 
     def fence(last_step=None):
         # a block of acquisitions cut short by the step count still owes its (partial) reduce
-        if use_dist and not strong and last_step is not None and last_step % rows != rows - 1:
-            blk = (last_step // rows) % nring
+        if use_dist and last_step is not None and last_step % per_block != per_block - 1:
+            blk = (last_step // per_block) % nring
             ring.submit(blk, async_op=False)
         ring.drain()
         if use_dist:
@@ -388,13 +495,13 @@ def main():
         i += 1
         if i % 4 == 0:
             torch.cuda.synchronize()
-            flag = torch.tensor([1.0 if time.perf_counter() - t0 < PREWARM_SECONDS else 0.0], device=dev)
+            flag = torch.tensor([1.0 if time.perf_counter() - t0 < PREWARM_SECONDS else 0.0], device=ctrl_dev)
             if use_dist:
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX)      # every rank leaves together
             if flag.item() == 0.0:
                 break
     prewarm_steps = i
-    fence(None if strong else i - 1)
+    fence(i - 1)
     for i in range(args.warmup):
         step(i)
     fence(args.warmup - 1 if args.warmup else None)
@@ -415,7 +522,7 @@ def main():
         elapsed = time.perf_counter() - t0
         my_regions.append(elapsed)
         if use_dist:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=ctrl_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         regions.append(elapsed)
@@ -428,7 +535,8 @@ def main():
     # ---- C5: the reduced spectra of the last scan against the committed fixtures -----------------
     check = None
     if strong and rank == 0 and not args.shard_as:
-        got = d_pwr[last_blk].cpu().numpy()
+        last_sub = (args.steps - 1) % per_block
+        got = d_pwr[last_blk][last_sub * hops:(last_sub + 1) * hops].cpu().numpy()
         worst = 0.0
         for hop in range(hops):
             g = np.load(os.path.join(ROOT, "tests", "golden", "c5_hop%d_n4096_r5000.npz" % hop))
@@ -531,16 +639,26 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc + ", u8 IQ resident in HBM (%d replay buffers of %d B per GPU)" % (nb, step_bytes),
+                       "workload_name": name, "workload_selected": selected,
                        "launch": info,
                        "shards_of_rank0": [list(m) for m in mine] if strong else None,
-                       "reduce": ("one async RCCL reduce of %d x %d f64 bins per %s" % (
-                           rows, N, "scan" if strong else "8 steps")) if use_dist else "none"},
+                       "reduce": ("one async %s reduce of %d x %d f64 bins per %s" % (
+                           "gloo (staged through pinned host memory)" if gloo else "RCCL",
+                           rows, N, ("%d scans" % per_block if per_block > 1 else "scan") if strong else "8 steps"))
+                       if use_dist else "none"},
             "timing": {"prewarm_steps": prewarm_steps, "regions_s": regions, "reported": "median region",
                        "min_region_s": min(regions), "max_region_s": max(regions)},
             "roofline": roof,
         }
         if use_dist:
             out["per_rank"] = per_rank
+        if args.share_device:
+            out["rehearsal"] = ("%d ranks share device 0 and time-slice it; the exchange is a gloo reduce staged through "
+                                "the host: launcher, shards, ring reuse, per-rank reports and the fixture check are what "
+                                "this run exercises -- `value` says nothing about scaling" % world)
+        if args.shard_as:
+            out["shard_as"] = {"ranks": args.shard_as, "what": "only the shard rank 0 of a job of that many ranks would own; "
+                               "ms_per_step = that rank's step on this GPU's clock; `value` is not a throughput"}
         if check:
             out["check"] = check
         if one_gpu:
@@ -557,6 +675,7 @@ def main():
         print(json.dumps(out), file=json_out, flush=True)
 
     ds.close()
+    ring.close()
     if use_dist:
         dist.destroy_process_group()
 

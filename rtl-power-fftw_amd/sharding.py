@@ -42,6 +42,21 @@ def reduce_power(pwr, dst=0, group=None, async_op=False):
     return dist.reduce(pwr, dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
+class _StagedWork:
+    """What `ScanRing.pending` holds for a host-staged reduce: `.wait()` like a torch Work."""
+
+    def __init__(self):
+        import threading
+        self._done = threading.Event()
+        self.error = None
+
+    def wait(self):
+        self._done.wait()
+        if self.error is not None:
+            raise self.error
+        return True
+
+
 class ScanRing:
     """The exchange step of a sharded scan: a ring of blocks of `rows` x N
     double accumulators.  A rank fills the rows it owns of block k (its kernels write them),
@@ -51,9 +66,16 @@ class ScanRing:
     reduce and, on `dst`, clears the block -- after a reduce `dst` holds the SUM, and the rows
     it does not own would otherwise be counted again next time round.
 
-    Works on any torch device / backend (RCCL on GPUs in bench.py, gloo on CPU in the tests)."""
+    Works on any torch device / backend (RCCL on GPUs in bench.py, gloo on CPU in the tests).
 
-    def __init__(self, rows, N, device, nring=4, dst=0, enabled=True, clear_on_reuse=True):
+    `host_staged=True` is the rehearsal form for boxes with fewer GPUs than ranks (gloo has no
+    reduce for device tensors): a worker thread waits for the block's kernels (an event on the
+    submitting stream), copies the block to a pinned host twin, reduces the twin over a process
+    group of its own -- every reduce of that group is issued by this one thread, in submit order,
+    so the main thread's barriers and all-reduces cannot interleave with them differently on
+    different ranks -- and, on `dst`, copies the sum back into the device block."""
+
+    def __init__(self, rows, N, device, nring=4, dst=0, enabled=True, clear_on_reuse=True, host_staged=False):
         import torch
         self.blocks = [torch.zeros(rows, N, dtype=torch.float64, device=device) for _ in range(nring)]
         self.pending = [None] * nring
@@ -63,6 +85,20 @@ class ScanRing:
         self.clear_on_reuse = clear_on_reuse
         self.wait_seconds = 0.0        # host time spent waiting for a block's previous reduce (bench.py reports it)
         self.waits = 0
+        self.host_staged = bool(host_staged and enabled)
+        if self.host_staged:
+            import queue
+            import threading
+            import torch.distributed as dist
+            self._on_gpu = torch.device(device).type == "cuda"
+            self._host = [torch.zeros(rows, N, dtype=torch.float64) for _ in range(nring)]
+            if self._on_gpu:
+                self._host = [h.pin_memory() for h in self._host]
+                self._side = torch.cuda.Stream(device=device)
+            self._group = dist.new_group(backend="gloo")
+            self._jobs = queue.Queue()
+            self._thread = threading.Thread(target=self._staging_loop, name="scan-ring-staging", daemon=True)
+            self._thread.start()
 
     def __len__(self):
         return len(self.blocks)
@@ -87,12 +123,60 @@ class ScanRing:
         """All of this rank's rows of block k are written (or enqueued on the current stream)."""
         if not self.enabled:
             return None
-        w = reduce_power(self.blocks[k], dst=self.dst, async_op=async_op)
+        if self.host_staged:
+            w = _StagedWork()
+            ready = None
+            if self._on_gpu:
+                import torch
+                ready = torch.cuda.Event()
+                ready.record()                      # after this rank's kernels of block k on the current stream
+            self._jobs.put((k, ready, w))
+            if not async_op:
+                w.wait()
+        else:
+            w = reduce_power(self.blocks[k], dst=self.dst, async_op=async_op)
         self.pending[k] = w if async_op else None
         return w
+
+    def _staging_loop(self):
+        import torch
+        import torch.distributed as dist
+        if self._on_gpu:
+            torch.cuda.set_device(self.blocks[0].device)      # a new thread starts on device 0
+        while True:
+            job = self._jobs.get()
+            if job is None:
+                return
+            k, ready, w = job
+            try:
+                if self._on_gpu:
+                    with torch.cuda.stream(self._side):
+                        self._side.wait_event(ready)
+                        self._host[k].copy_(self.blocks[k], non_blocking=True)
+                    self._side.synchronize()
+                else:
+                    self._host[k].copy_(self.blocks[k])
+                dist.reduce(self._host[k], dst=self.dst, op=dist.ReduceOp.SUM, group=self._group)
+                if dist.get_rank() == self.dst:
+                    if self._on_gpu:
+                        with torch.cuda.stream(self._side):
+                            self.blocks[k].copy_(self._host[k], non_blocking=True)
+                        self._side.synchronize()
+                    else:
+                        self.blocks[k].copy_(self._host[k])
+            except Exception as exc:            # surfaces in wait(): a failed reduce must not look like a finished one
+                w.error = exc
+            w._done.set()
 
     def drain(self):
         for k in range(len(self.blocks)):
             if self.pending[k] is not None:
                 self.pending[k].wait()
                 self.pending[k] = None
+
+    def close(self):
+        """Stop the staging thread (host-staged form); the ring must be drained first."""
+        if self.host_staged and self._thread is not None:
+            self._jobs.put(None)
+            self._thread.join()
+            self._thread = None

@@ -77,12 +77,12 @@ def test_two_rank_scan_equals_single_process(tmp_path, world):
         assert max_rel(got[hop], want) < 1e-13
 
 
-def _ring_worker(rank, world, port, out):
+def _ring_worker(rank, world, port, out, host_staged=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     hops, n, scans = 8, 16, 11                          # more scans than ring slots: blocks are reused
-    ring = rpf.sharding.ScanRing(hops, n, "cpu", nring=3, dst=0)
+    ring = rpf.sharding.ScanRing(hops, n, "cpu", nring=3, dst=0, host_staged=host_staged)
     mine = rpf.sharding.shard_hops(hops, 10, world, rank)
     for s in range(scans):
         k = s % len(ring)
@@ -90,6 +90,10 @@ def _ring_worker(rank, world, port, out):
         for hop, first, count in mine:                  # this rank's share of hop `hop`: count/10 of its power
             blk[hop] = float(s + 1) * (hop + 1) * count / 10.0
         ring.submit(k)
+        if host_staged and s % 4 == 1:                  # the main thread's own collectives, between the staging
+            t = torch.ones(1)                           # thread's reduces (bench.py: flags, region times, barriers)
+            dist.all_reduce(t)
+            assert t.item() == world
         if s >= 2:                                      # read a scan that is two submits old (still in the ring)
             j = (s - 2) % len(ring)
             ring.pending[j] and ring.pending[j].wait()
@@ -97,13 +101,15 @@ def _ring_worker(rank, world, port, out):
                 want = float(s - 1) * (torch.arange(hops, dtype=torch.float64) + 1)
                 assert torch.allclose(ring.blocks[j][:, 0], want, rtol=1e-13), (s, ring.blocks[j][:, 0], want)
     ring.drain()
+    ring.close()
     if rank == 0:
         np.save(out, ring.blocks[(scans - 1) % len(ring)].numpy())
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("host_staged", [False, True])
 @pytest.mark.parametrize("world", [2, 3])
-def test_scan_ring_reuse_does_not_count_rows_twice(tmp_path, world):
+def test_scan_ring_reuse_does_not_count_rows_twice(tmp_path, world, host_staged):
     """bench.py's exchange (sharding.ScanRing): after a reduce rank 0 holds the SUM; the rows it
     does not own must be cleared before the block is filled again, or every reuse of a ring
     slot would add the previous scan's spectra once more."""
@@ -112,6 +118,8 @@ def test_scan_ring_reuse_does_not_count_rows_twice(tmp_path, world):
     port = s.getsockname()[1]
     s.close()
     out = str(tmp_path / "ring.npy")
-    mp.spawn(_ring_worker, args=(world, port, out), nprocs=world, join=True)
+    # host_staged: bench.py's one-GPU rehearsal form (--dist-backend gloo --share-device): a staging thread
+    # issues the reduces on a process group of its own while the main thread keeps using the default one
+    mp.spawn(_ring_worker, args=(world, port, out, host_staged), nprocs=world, join=True)
     got = np.load(out)
     assert np.allclose(got[:, 0], 11.0 * (np.arange(8) + 1), rtol=1e-13)

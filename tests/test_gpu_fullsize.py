@@ -232,11 +232,40 @@ def test_bench_c5_line_through_rccl_is_checked_against_the_fixtures():
 
 
 def test_bench_c5_two_ranks():
-    """Two processes, two GPUs: hop-major shards, one RCCL reduce per scan, reduced spectra checked."""
+    """`python bench.py --gpus 2`, no wrapper: bench.py starts the two ranks itself (two GPUs): hop-major
+    shards, one RCCL reduce per scan, reduced spectra checked."""
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("one GPU on this box: the 2-rank RCCL run needs two")
-    d = _bench_line(["--gpus", "2", "--steps", "8", "--warmup", "2"], nproc=2)
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    d = _bench_line(["--gpus", "2", "--steps", "8", "--warmup", "2"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["workload_name"] == "C5"
+    assert len(d["per_rank"]) == 2 and {p["rank"] for p in d["per_rank"]} == {0, 1}
     assert d["check"]["reduced_spectra_vs_float64_fixtures_max_rel"] < 1e-6
+    assert d["one_gpu_same_workload"]["value"] > 0
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """The shape of the driver's command with more GPUs than the box has: exit code 2 and NO line --
+    never a one-GPU measurement reported under a larger --gpus."""
+    import subprocess
+    import sys
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "4"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and r.stdout.strip() == ""
+    assert "%d ranks asked for" % n in r.stderr
+
+
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_bench_c5_rehearsal_ranks_share_one_gpu(ranks):
+    """The multi-rank run rehearsed on ONE GPU (`--dist-backend gloo --share-device`): bench.py's own launcher,
+    shard_hops, the ScanRing's reuse, per-rank reports and the fixture check of the REDUCED spectra, all on the
+    real kernels; only the exchange differs from the RCCL run (gloo, staged through the host)."""
+    d = _bench_line(["--gpus", str(ranks), "--dist-backend", "gloo", "--share-device", "--steps", "8", "--warmup", "2"])
+    assert d["n_gpus"] == ranks and d["scaling"] == "strong" and d["config"]["workload_name"] == "C5"
+    assert "rehearsal" in d and "gloo" in d["config"]["reduce"]
+    assert len(d["per_rank"]) == ranks and sorted(p["rank"] for p in d["per_rank"]) == list(range(ranks))
+    assert sum(p["frames_per_step"] for p in d["per_rank"]) == 8 * 5000
+    assert d["check"]["hops"] == 8 and d["check"]["reduced_spectra_vs_float64_fixtures_max_rel"] < 1e-6
     assert d["one_gpu_same_workload"]["value"] > 0

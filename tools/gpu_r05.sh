@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round 5's GPU jobs, one script, selected by its first argument (gpurun -- 'bash tools/gpu_r05.sh <job>'):
+#   ranks     bench.py's self-launched multi-rank runs rehearsed on one GPU (2/4/8 ranks, gloo, shared device),
+#             the per-rank step of a 2/4/8-rank C5 job (--shard-as), and the launcher tests
+#   fused     the fused four-step kernel's abort / fall-back tests and C4 bench on both paths
+#   stream    the buffer-queue rates (bench.py's end_to_end leg + tools/queue_rate)
+#   final     tools/gpu_final_check.sh
+set -u
+ROOT=$GRAFT_REPO_ROOT
+OUT=$ROOT/gpurun_out/r05
+mkdir -p $OUT
+cd $ROOT
+job=${1:-ranks}
+case $job in
+ranks)
+  timeout 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q -k "bench" > $OUT/ranks_pytest.log 2>&1; echo "pytest rc=$?"; tail -5 $OUT/ranks_pytest.log
+  for n in 2 4 8; do
+    timeout 600 python bench.py --gpus $n --dist-backend gloo --share-device --steps 50 --warmup 5 > $OUT/c5_${n}rank_gloo.json 2> $OUT/c5_${n}rank_gloo.err; echo "rehearsal $n ranks rc=$?"
+    python3 -c "import json;d=json.load(open('$OUT/c5_${n}rank_gloo.json'));print(d['n_gpus'], d['value']/1e9, d['check'], [ (p['rank'],p['frames_per_step'],round(p['kernel_ms_median'],4)) for p in d['per_rank']])"
+  done
+  for n in 1 2 4 8; do
+    timeout 300 python bench.py --workload C5 --shard-as $n --no-cpu-baseline --no-end-to-end > $OUT/c5_shard_as$n.json 2> $OUT/c5_shard_as$n.err; echo "shard-as $n rc=$?"
+    python3 -c "import json;d=json.load(open('$OUT/c5_shard_as$n.json'));print('shard-as $n: ms_per_step', d['ms_per_step'], 'kernel_ms', d['roofline']['kernel_ms'])"
+  done
+  for n in 2 4 8; do
+    timeout 300 python bench.py --workload C5 --shard-as $n --force-dist --no-cpu-baseline --no-end-to-end > $OUT/c5_shard_as${n}_rccl.json 2> $OUT/c5_shard_as${n}_rccl.err; echo "shard-as $n rccl rc=$?"
+    python3 -c "import json;d=json.load(open('$OUT/c5_shard_as${n}_rccl.json'));print('shard-as $n + 1-rank RCCL reduce: ms_per_step', d['ms_per_step'])"
+  done
+  ;;
+final)
+  shift; bash tools/gpu_final_check.sh "$@"
+  ;;
+*) echo "unknown job $job"; exit 1;;
+esac
