@@ -608,10 +608,13 @@ def main():
                     measured_peak = tj.get("measured_read_only_GBps")   # tools/hbm_read_bench.hip, same box type
                 except Exception:
                     traffic = None
+            # (which four-step kernel ran is what the ENGINE says -- rpf_fused_status --, not what the flags asked for:
+            #  an engine whose teams did not assemble at creation is on the two-kernel path)
+            fused = ds.fused_status()
             kernel = ("fft_accum_kernel<N=4096,P=16> (K1)" if N == 4096 else
-                      "fourstep transform of one acquisition (two-kernel path: all batches of the column/row kernels)"
-                      if args.engine_flags & 8 else
-                      "fourstep_fused_kernel<Split<512,512>> (one persistent launch per acquisition, Y handed over in the XCDs' L2)")
+                      "fourstep_fused_kernel<Split<512,512>> (one persistent launch per acquisition, Y handed over in the XCDs' L2)"
+                      if fused["active"] else
+                      "fourstep transform of one acquisition (two-kernel path: all batches of the column/row kernels)")
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "traffic_source": ("NOT measured in this run: rocprofv3 PMC capture replayed from profiles/traffic.json -- "
@@ -619,6 +622,7 @@ def main():
                     "kernel": kernel, "kernel_ms": k1_ms, "kernel_ms_mean": k1_mean_ms, "kernel_ms_samples": len(events),
                     "algorithmic_bytes_per_launch": alg_bytes, "frames_per_launch": frames_per_launch,
                     "hops_per_launch": hops_per_launch,
+                    "fused_four_step": fused if N != 4096 else None,
                     "samples_per_s_kernel_only": N * frames_per_launch / (k1_ms * 1e-3),
                     # the contracted roofline is HBM read; what actually limits the kernel:
                     "limited_by": "fp32-valu + lds (see secondary): ~55 flop/B against a machine balance of ~20",

@@ -62,8 +62,17 @@ typedef struct rpf_config {
  * 32768 default to the LDS mixed-radix kernels -- windowed runs of 32768 excepted, which are faster here -- so asking for
  * it is also asking for the four-step path) whenever
  * its eight workgroup teams assemble at rpf_engine_create; otherwise the engine keeps the two-kernel path.  A launch
- * whose teams do not assemble later (a CU held by someone else's kernel for ~0.5 s) NaN-fills the spectrum and
- * rpf_finish reports RPF_ERR_HARDWARE: loud, never wrong.   */
+ * whose teams do not assemble later (a CU held by someone else's kernel for seconds: another process on the device)
+ * gives up, and the engine leaves the fused kernel for the rest of its life:
+ *   - buffer-queue path (rpf_begin .. rpf_finish, rpf_accumulate): the acquisition does NOT fail -- like the
+ *     reference's worker (datastore.cxx:48-96) this one has no failure path for it.  K3 leaves the accumulator alone,
+ *     the worker runs the same staged bytes through the two-kernel path and rpf_finish returns RPF_OK with the spectrum
+ *     that path gives (bit-identical to RPF_FLAG_NO_FOURSTEP_FUSED whenever every fused launch in flight gave up,
+ *     else equal up to the order of the double additions);
+ *   - device-resident entries (rpf_accumulate_device*, rpf_device_*; they return without synchronising): d_pwr_out of
+ *     THAT launch is NaN-filled -- loud, never wrong -- and the next entry (or rpf_fused_status) that runs after the
+ *     caller's stream has passed the launch notices and switches to the two-kernel path; see rpf_fused_status.
+ *  */
 #define RPF_FLAG_FOURSTEP_FUSED 2u
 /* The four-step sizes on the two-kernel path (intermediate through HBM) even where the fused kernel is available
  * (A/B measurement, and the fallback's own tests). */
@@ -136,7 +145,9 @@ int rpf_accumulate(rpf_engine* e, const uint8_t* stream, size_t nbytes, int64_t 
  * LDS-DMA staging path, other alignments silently stage through VGPRs).  The
  * engine's device is made current for the call and the caller's restored.  Enqueues the fused kernel and the partial-sum reduce on
  * `hip_stream` (a hipStream_t; NULL = HIP's null stream) and returns
- * without synchronising; d_pwr_out[N] (device doubles, 16-byte aligned -- the reduce stores
+ * without synchronising (one exception: the two-kernel four-step and large Bluestein paths grow their intermediate to
+ * what a launch needs -- a call that needs more than any before it synchronises `hip_stream` once, frees and
+ * allocates); d_pwr_out[N] (device doubles, 16-byte aligned -- the reduce stores
  * bin pairs -- else RPF_ERR_INVALID_ARGUMENT; the same holds for every d_pwr_out below) is
  * overwritten with the sum over frames [0, min(repeats, nbytes/(2N))).  Used by bench.py and the
  * full-size parity tests; does not touch the buffer queues. */
@@ -191,6 +202,21 @@ const char* rpf_scan_reducer_last_error(const rpf_scan_reducer* r);
 int rpf_scan_reducer_begin(rpf_scan_reducer* r);
 int rpf_scan_reducer_deposit(rpf_scan_reducer* r, int slot, int hop, const rpf_engine* e);
 int rpf_scan_reducer_reduce(rpf_scan_reducer* r, int hops, double* host_out /* hops x N */);
+
+/* Which four-step kernel this engine runs, and what became of its fused launches.
+ *   *active            1: the fused persistent kernel is what the next launch runs; 0: the two-kernel path (or N is not
+ *                      a four-step size)
+ *   *launches_gave_up  fused launches whose teams did not assemble, over the engine's life.  Device-resident entries:
+ *                      read it after synchronising the stream; a count that has grown means the spectrum of that
+ *                      launch is NaN and must be asked for again (the engine is on the two-kernel path by then).
+ *   *launches_recovered  of those, the ones the buffer-queue worker ran again on the two-kernel path
+ * Any pointer may be NULL.  Not to be called while an acquisition is running. */
+int rpf_fused_status(const rpf_engine* e, int* active, int64_t* launches_gave_up, int64_t* launches_recovered);
+/* Test hook (tests/test_gpu_fused_abort.py): sabotage fused launches -- after `skip` untouched ones the next
+ * `count` (< 0: all) launches fail to assemble.  mode 1: the launch finds a 33rd workgroup on XCD 0 and gives up at
+ * once; mode 2: one CU is held by a squatter kernel until the launch has given up (the real failure, seconds);
+ * mode 0: disarm.  No effect on an engine that is not on the fused kernel. */
+int rpf_debug_fused_fault(rpf_engine* e, int mode, int skip, int count);
 
 /* Launch geometry of the last fused-kernel launch (for DESIGN/bench reporting):
  * workgroups, threads per workgroup, frames per workgroup, LDS bytes. */

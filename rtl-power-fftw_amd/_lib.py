@@ -87,6 +87,9 @@ _SYMBOLS = [
     ("rpf_scan_reducer_begin", ctypes.c_int, [_P]),
     ("rpf_scan_reducer_deposit", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P]),
     ("rpf_scan_reducer_reduce", ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+    ("rpf_fused_status", ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64),
+                                        ctypes.POINTER(ctypes.c_int64)]),
+    ("rpf_debug_fused_fault", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     ("rpf_last_launch_info", ctypes.c_int, [_P] + [ctypes.POINTER(ctypes.c_int)] * 4),
 ]
 

@@ -47,6 +47,7 @@ struct HostBuffer {
     hipEvent_t copied = nullptr;    // its H2D copy has finished: the producer may refill it
 };
 
+constexpr int kStagingSlots = 3;    // device staging ring: one slot filling, one waiting for its kernel, one running
 constexpr int kCopyStreams = 2;     // H2D copies alternate between two streams (two SDMA queues): no gap between copies
 
 struct StagingSlot {
@@ -54,6 +55,12 @@ struct StagingSlot {
     hipEvent_t copy_done[kCopyStreams] = {};   // everything copied into the slot on that stream has landed
     hipEvent_t kernel_done = nullptr;
     bool in_flight = false;
+    // the last transform launched over the slot (still valid until the slot is reopened): what a fused launch that
+    // gave up is re-run on
+    const uint8_t* launch_ptr = nullptr;
+    int64_t launch_frames = 0;
+    bool launched_fused = false;
+    unsigned* verdict = nullptr;    // pinned host word the launch's verdict kernel sets to 1 if it gave up
 };
 
 }  // namespace
@@ -98,6 +105,16 @@ struct rpf_engine {
     bool fourstep = false;                // N handled by rpf_fourstep.hip
     bool fused = false;                   // ... by the fused persistent kernel (Y stays in the XCDs' L2)
     void* d_fused_ctl = nullptr;          // its team counters / abort flag
+    rpf::cf* d_fused_scratch = nullptr;   // its Y (two rounds per XCD); kept apart from d_scratch, the two-kernel path's
+    // What became of the fused launches, written by their verdict kernels into pinned host memory:
+    // [0 .. 2] one word per staging slot (queue path), [3] launches of the device-resident entries that gave up
+    // (cumulative), [4] all launches that gave up (cumulative).
+    unsigned* h_fused_words = nullptr;
+    unsigned* d_fused_words = nullptr;    // the same words as the device addresses them
+    bool last_was_fused = false;          // the last transform launched was the fused kernel
+    unsigned fused_aborts_seen = 0;       // h_fused_words[3] when the host last looked
+    int64_t fused_recovered = 0;          // launches re-run on K2a/K2b after giving up (queue path)
+    int fused_fault_mode = 0, fused_fault_skip = 0, fused_fault_count = 0;   // rpf_debug_fused_fault
     bool bluestein = false;               // N handled by the Bluestein kernel (chirp tables below)
     bool bigblu = false;                  // N handled by the large (four-step) Bluestein path
     bool mixed = false;                   // N handled by the LDS mixed-radix kernel (rpf_mixed.hip)
@@ -248,11 +265,37 @@ int ensure_scratch(rpf_engine* e, int64_t nframes, hipStream_t stream)
         e->scratch_bytes = want;
     } else {
         (void)hipGetLastError();
-        HIP_TRY(e, hipMalloc(&p, had));
-        e->scratch_bytes = had;
+        // what there was before, or (nothing yet: an engine that has just left the fused kernel) one frame's worth
+        const size_t least = std::max(had, e->scratch_per_frame);
+        HIP_TRY(e, hipMalloc(&p, least));
+        e->scratch_bytes = least;
     }
     e->d_scratch = static_cast<rpf::cf*>(p);
     return RPF_OK;
+}
+
+// This engine keeps to K2a/K2b from here on (a fused launch gave up).  Nothing is freed -- launches in flight may
+// still be using the fused kernel's scratch --; the two-kernel path's intermediate is allocated by ensure_scratch at
+// its first launch (one stream synchronisation).
+void retire_fused(rpf_engine* e)
+{
+    if (!e->fused) return;
+    e->fused = false;
+    e->scratch_per_frame = rpf::fourstep_scratch_bytes_per_frame(e->N);
+    e->scratch_max = rpf::fourstep_scratch_bytes(e->N);
+}
+
+// The device-resident entries return without synchronising, so a launch of theirs that gave up is found out later:
+// its verdict kernel has counted it in pinned host memory by the time the caller's stream has passed it.  Every
+// later entry looks (no synchronisation) and retires the fused kernel once it sees a count it has not seen.
+void note_device_path_aborts(rpf_engine* e)
+{
+    if (!e->h_fused_words) return;
+    const unsigned now = __atomic_load_n(&e->h_fused_words[3], __ATOMIC_ACQUIRE);
+    if (now != e->fused_aborts_seen) {
+        e->fused_aborts_seen = now;
+        retire_fused(e);
+    }
 }
 
 // Enqueue K1 (or the four-step pair K2a/K2b) for `nframes` frames starting at
@@ -261,12 +304,23 @@ int launch_transform(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, hi
                      int* nslots)
 {
     const uintptr_t addr = reinterpret_cast<uintptr_t>(d_frames);
+    e->last_was_fused = false;
     if (e->fourstep && e->fused) {
         const bool dma = e->use_dma && (addr % 4) == 0;
+        int fault = 0;                       // rpf_debug_fused_fault: `count` launches after `skip` untouched ones
+        if (e->fused_fault_count != 0) {
+            if (e->fused_fault_skip > 0) {
+                --e->fused_fault_skip;
+            } else {
+                fault = e->fused_fault_mode;
+                if (e->fused_fault_count > 0) --e->fused_fault_count;
+            }
+        }
         HIP_TRY(e, rpf::launch_fourstep_fused(e->N, e->has_window, dma, d_frames, nframes, e->d_tw_sub, e->d_tw_sub2,
-                                              e->d_twiddles, e->d_window, e->d_scratch, e->d_partial,
-                                              e->d_fused_ctl, stream));
+                                              e->d_twiddles, e->d_window, e->d_fused_scratch, e->d_partial,
+                                              e->d_fused_ctl, stream, fault));
         e->last = e->plan;
+        e->last_was_fused = true;
         *nslots = rpf::fourstep_fused_slots(e->N);
         return RPF_OK;
     }
@@ -319,19 +373,27 @@ int launch_transform(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, hi
 }
 
 // Transform + reduce for `nframes` frames starting at d_frames.
+// slot_verdict: the queue path's pinned word for this launch -- if a fused launch gives up, K3 leaves d_out as it
+// is, the word becomes 1 and the worker re-runs the bytes on K2a/K2b (recover_fused); null (the device-resident
+// entries): d_out is NaN-filled and the launch counted in h_fused_words[3].
 int launch_frames(rpf_engine* e, const uint8_t* d_frames, int64_t nframes, double* d_out,
-                  bool accumulate, hipStream_t stream)
+                  bool accumulate, hipStream_t stream, unsigned* slot_verdict = nullptr)
 {
     if (nframes <= 0) return RPF_OK;
+    if (e->fused && !slot_verdict) note_device_path_aborts(e);
     int nslots = 0;
     int rc = launch_transform(e, d_frames, nframes, stream, &nslots);
     if (rc != RPF_OK) return rc;
     e->last_slots = nslots;
     e->last_hops = 0;
+    const bool fused = e->last_was_fused;
     HIP_TRY(e, rpf::launch_reduce(e->d_partial, nslots, e->N, d_out, accumulate, stream,
-                                  e->plan.partial_f32, e->bigblu ? static_cast<size_t>(e->blu_M) : 0));
+                                  e->plan.partial_f32, e->bigblu ? static_cast<size_t>(e->blu_M) : 0,
+                                  fused && slot_verdict ? rpf::fourstep_fused_abort_word(e->d_fused_ctl) : nullptr));
     // a fused launch whose teams did not assemble must not leave something that looks like a spectrum
-    if (e->fused) HIP_TRY(e, rpf::launch_fused_poison(e->d_fused_ctl, d_out, e->N, stream));
+    if (fused)
+        HIP_TRY(e, rpf::launch_fused_verdict(e->d_fused_ctl, slot_verdict ? nullptr : d_out, e->N,
+                                             slot_verdict ? slot_verdict : e->d_fused_words + 3, e->d_fused_words + 4, stream));
     return RPF_OK;
 }
 
@@ -427,7 +489,37 @@ void worker_main(rpf_engine* e)
     bool used[kCopyStreams] = {};
     unsigned next_stream = 0;
 
+    // A fused four-step launch gave up (its teams did not assemble: rpf_fourstep.hip): K3 has left d_pwr alone and the
+    // slot still holds the launch's bytes.  Everything in flight is waited for, the engine leaves the fused kernel for
+    // good, and every slot whose launch gave up is run again on K2a/K2b, oldest first -- the order of the additions
+    // into d_pwr is the launch order whenever all fused launches in flight gave up (a device that has become busy),
+    // and differs from it by the place of the re-run terms otherwise (double addition: ~1e-16 relative).
+    // The reference's worker has no failure path (datastore.cxx:48-96); neither has this one for this cause.
+    auto recover_fused = [&](size_t oldest) {
+        WORKER_TRY(hipStreamSynchronize(e->compute_stream), "hipStreamSynchronize(recover)");
+        retire_fused(e);
+        for (size_t k = 0; k < e->staging.size(); ++k) {
+            StagingSlot& s = e->staging[(oldest + k) % e->staging.size()];
+            if (!s.launched_fused || !s.verdict || __atomic_load_n(s.verdict, __ATOMIC_ACQUIRE) == 0) continue;
+            *s.verdict = 0;
+            s.launched_fused = false;
+            if (!ok()) continue;
+            int rc = launch_frames(e, s.launch_ptr, s.launch_frames, e->d_pwr, /*accumulate=*/true, e->compute_stream);
+            if (rc != RPF_OK) {
+                e->worker_rc = rc;
+                e->worker_error = e->last_error;
+            }
+            ++e->fused_recovered;
+        }
+        // (the re-runs read the slots: nothing may be copied into one before they are done)
+        WORKER_TRY(hipStreamSynchronize(e->compute_stream), "hipStreamSynchronize(recover)");
+        for (auto& s : e->staging) s.in_flight = false;
+    };
+    auto gave_up = [&](const StagingSlot& s) {
+        return s.launched_fused && s.verdict && __atomic_load_n(s.verdict, __ATOMIC_ACQUIRE) != 0;
+    };
     auto open_slot = [&]() {
+        const size_t idx = slot_idx;
         cur = &e->staging[slot_idx];
         slot_idx = (slot_idx + 1) % e->staging.size();
         // The slot is free once its own kernel AND the following slot's carry copy (which read its tail) are done;
@@ -437,7 +529,9 @@ void worker_main(rpf_engine* e)
             if (!s->in_flight) continue;
             WORKER_TRY(hipEventSynchronize(s->kernel_done), "hipEventSynchronize(kernel_done)");
             s->in_flight = false;
+            if (gave_up(*s)) recover_fused(idx);        // (`cur` is the oldest slot in flight)
         }
+        cur->launched_fused = false;
         off = 0;
         for (bool& u : used) u = false;
     };
@@ -457,11 +551,15 @@ void worker_main(rpf_engine* e)
         int64_t nframes = static_cast<int64_t>(avail / frame_bytes);
         nframes = std::min<int64_t>(nframes, e->repeats - frames_issued);    // datastore.cxx:67
         if (ok() && nframes > 0) {
-            int rc = launch_frames(e, dst - carry, nframes, e->d_pwr, /*accumulate=*/true, e->compute_stream);
+            if (cur->verdict) *cur->verdict = 0;
+            int rc = launch_frames(e, dst - carry, nframes, e->d_pwr, /*accumulate=*/true, e->compute_stream, cur->verdict);
             if (rc != RPF_OK) {
                 e->worker_rc = rc;
                 e->worker_error = e->last_error;
             }
+            cur->launch_ptr = dst - carry;
+            cur->launch_frames = nframes;
+            cur->launched_fused = rc == RPF_OK && e->last_was_fused;
             frames_issued += nframes;
         }
         WORKER_TRY(hipEventRecord(cur->kernel_done, e->compute_stream), "hipEventRecord(kernel_done)");
@@ -522,16 +620,16 @@ void worker_main(rpf_engine* e)
     }
 
     WORKER_TRY(hipStreamSynchronize(e->compute_stream), "hipStreamSynchronize");
-    if (e->fused && ok()) {
-        // a fused launch whose teams did not assemble has NaN-filled the spectrum: that is an error, not a result
-        bool aborted = false;
-        WORKER_TRY(rpf::fourstep_fused_aborted(e->d_fused_ctl, e->compute_stream, &aborted), "fourstep_fused_aborted");
-        if (ok() && aborted) {
-            e->worker_rc = RPF_ERR_HARDWARE;
-            e->worker_error = "the fused four-step kernel's workgroup teams did not assemble (device busy?)";
+    // the launches still in flight at the end: any fused one that gave up is re-run now (slot_idx = the oldest slot)
+    for (const auto& s : e->staging)
+        if (ok() && gave_up(s)) {
+            recover_fused(slot_idx);
+            break;
         }
+    for (auto& s : e->staging) {
+        s.in_flight = false;
+        s.launched_fused = false;
     }
-    for (auto& s : e->staging) s.in_flight = false;
     WORKER_TRY(hipMemcpy(e->pwr.data(), e->d_pwr, sizeof(double) * e->N, hipMemcpyDeviceToHost), "hipMemcpy(pwr)");
     e->repeats_done = frames_issued;
 #undef WORKER_TRY
@@ -544,6 +642,8 @@ void release_device(rpf_engine* e)
     if (e->d_tw_sub2) (void)hipFree(e->d_tw_sub2);
     if (e->d_scratch) (void)hipFree(e->d_scratch);
     if (e->d_fused_ctl) (void)hipFree(e->d_fused_ctl);
+    if (e->d_fused_scratch) (void)hipFree(e->d_fused_scratch);
+    if (e->h_fused_words) (void)hipHostFree(e->h_fused_words);
     if (e->d_step2) (void)hipFree(e->d_step2);
     if (e->d_chirp) (void)hipFree(e->d_chirp);
     if (e->d_bhat) (void)hipFree(e->d_bhat);
@@ -747,10 +847,14 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         int fused_grid = 0;
         if (!(cfg->flags & RPF_FLAG_NO_FOURSTEP_FUSED) &&
             rpf::fourstep_fused_prepare(e->N, e->device, &fused_grid) == hipSuccess) {
-            CREATE_TRY(hipMalloc(&e->d_scratch, rpf::fourstep_fused_scratch_bytes(e->N)));
+            CREATE_TRY(hipMalloc(&e->d_fused_scratch, rpf::fourstep_fused_scratch_bytes(e->N)));
             CREATE_TRY(hipMalloc(&e->d_fused_ctl, rpf::fourstep_fused_ctl_bytes()));
+            CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_fused_words), 64, hipHostMallocMapped));
+            std::memset(e->h_fused_words, 0, 64);
+            CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->d_fused_words), e->h_fused_words, 0));
             e->fused = true;
-            partial_slots = rpf::fourstep_fused_slots(e->N);
+            // (room for either path's partial spectra: a fused launch that gives up is re-run on K2a/K2b)
+            partial_slots = std::max<size_t>(rpf::fourstep_fused_slots(e->N), rpf::fourstep_partial_slots(e->N));
         } else {
             (void)hipGetLastError();
             e->scratch_per_frame = rpf::fourstep_scratch_bytes_per_frame(e->N);
@@ -790,21 +894,16 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         bool aborted = true;
         hipError_t lerr = rpf::launch_fourstep_fused(e->N, e->has_window, true, static_cast<const uint8_t*>(d_dummy),
                                                      static_cast<long>(round_bytes / (2u * static_cast<size_t>(e->N))),
-                                                     e->d_tw_sub, e->d_tw_sub2, e->d_twiddles, e->d_window, e->d_scratch,
+                                                     e->d_tw_sub, e->d_tw_sub2, e->d_twiddles, e->d_window, e->d_fused_scratch,
                                                      e->d_partial, e->d_fused_ctl, e->compute_stream);
         if (lerr == hipSuccess) lerr = rpf::fourstep_fused_aborted(e->d_fused_ctl, e->compute_stream, &aborted);
         if (lerr != hipSuccess || aborted) {
             (void)hipGetLastError();
-            e->fused = false;
-            (void)hipFree(e->d_scratch);
-            e->d_scratch = nullptr;
-            (void)hipFree(e->d_partial);
-            e->d_partial = nullptr;
-            e->scratch_per_frame = rpf::fourstep_scratch_bytes_per_frame(e->N);
-            e->scratch_max = rpf::fourstep_scratch_bytes(e->N);
+            retire_fused(e);
+            (void)hipFree(e->d_fused_scratch);          // (nothing is in flight here)
+            e->d_fused_scratch = nullptr;
             e->scratch_bytes = std::min<size_t>(e->scratch_max, static_cast<size_t>(256) << 20);
             CREATE_TRY(hipMalloc(&e->d_scratch, e->scratch_bytes));
-            CREATE_TRY(hipMalloc(&e->d_partial, sizeof(double) * e->N * std::max<size_t>(partial_slots, rpf::fourstep_partial_slots(e->N))));
         }
     }
 
@@ -823,7 +922,7 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
     // a slot (= one transform launch) holds as many buffers as fit 32 MB, at least one -- more than the pool has where the
     // buffers are small: they return to the producer when their copy lands, not when the slot is launched
     e->coalesce = std::max<size_t>(1, (32u << 20) / e->buffer_capacity);
-    e->staging.resize(3);
+    e->staging.resize(kStagingSlots);
     for (auto& s : e->staging) {
         void* p = nullptr;
         CREATE_TRY(hipMalloc(&p, e->head_room + e->coalesce * e->buffer_capacity));
@@ -831,6 +930,9 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
         CREATE_TRY(hipEventCreateWithFlags(&s.kernel_done, hipEventDisableTiming));
         for (hipEvent_t& ev : s.copy_done) CREATE_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
+    static_assert(kStagingSlots <= 3, "h_fused_words[0 .. 2]: one verdict word per staging slot");
+    if (e->h_fused_words)
+        for (size_t k = 0; k < e->staging.size(); ++k) e->staging[k].verdict = e->h_fused_words + k;
 #undef CREATE_TRY
     *out = e;
     return RPF_OK;
@@ -1085,6 +1187,7 @@ int rpf_device_fused(rpf_engine* e, const void* d_stream, size_t nbytes, int64_t
     nframes = std::min(nframes, repeats);
     if (nframes < 1) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_device_fused: no whole frame");
     if (repeats_done) *repeats_done = nframes;
+    if (e->fused) note_device_path_aborts(e);
     int nslots = 0;
     int rc = launch_transform(e, static_cast<const uint8_t*>(d_stream), nframes,
                               static_cast<hipStream_t>(hip_stream), &nslots);
@@ -1111,7 +1214,9 @@ int rpf_device_reduce(rpf_engine* e, double* d_pwr_out, void* hip_stream)
     HIP_TRY(e, rpf::launch_reduce(e->d_partial, e->last_slots, e->N, d_pwr_out,
                                   /*accumulate=*/false, static_cast<hipStream_t>(hip_stream),
                                   e->plan.partial_f32, e->bigblu ? static_cast<size_t>(e->blu_M) : 0));
-    if (e->fused) HIP_TRY(e, rpf::launch_fused_poison(e->d_fused_ctl, d_pwr_out, e->N, static_cast<hipStream_t>(hip_stream)));
+    if (e->last_was_fused)
+        HIP_TRY(e, rpf::launch_fused_verdict(e->d_fused_ctl, d_pwr_out, e->N, e->d_fused_words + 3, e->d_fused_words + 4,
+                                             static_cast<hipStream_t>(hip_stream)));
     return RPF_OK;
 }
 
@@ -1208,6 +1313,27 @@ int rpf_device_fused_hops(rpf_engine* e, const void* const* d_streams, const siz
     if (rc != RPF_OK) return rc;
     e->last_slots = nslots;
     e->last_hops = n_hops;
+    return RPF_OK;
+}
+
+int rpf_fused_status(const rpf_engine* e, int* active, int64_t* launches_gave_up, int64_t* launches_recovered)
+{
+    if (!e) return RPF_ERR_INVALID_ARGUMENT;
+    rpf_engine* me = const_cast<rpf_engine*>(e);
+    if (me->fused && !me->worker_running) note_device_path_aborts(me);
+    if (active) *active = (e->fourstep && e->fused) ? 1 : 0;
+    if (launches_gave_up) *launches_gave_up = e->h_fused_words ? __atomic_load_n(&e->h_fused_words[4], __ATOMIC_ACQUIRE) : 0;
+    if (launches_recovered) *launches_recovered = e->fused_recovered;
+    return RPF_OK;
+}
+
+int rpf_debug_fused_fault(rpf_engine* e, int mode, int skip, int count)
+{
+    if (!e || mode < 0 || mode > 2 || skip < 0) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_debug_fused_fault: bad argument");
+    if (e->worker_running) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_debug_fused_fault: acquisition running");
+    e->fused_fault_mode = mode;
+    e->fused_fault_skip = skip;
+    e->fused_fault_count = mode ? count : 0;
     return RPF_OK;
 }
 

@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <mutex>
 #include <cstdlib>
+#include <thread>
 
 #include "fused_layout.h"
 #include "rpf_device_common.h"
@@ -286,8 +287,11 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_rows_kernel(const cf* __restr
 // ---- fused four-step: the intermediate is read back from the writing XCD's L2 --------------------
 // K2a/K2b above exchange Y through the fabric: 8 B written + 8 B read per sample against 2 algorithmic bytes,
 // and the pair runs at the speed of that traffic.  What the L2 offers (profiles/r04_l2_residency.txt):
-// every stored byte still leaves it (write-through), but a line stored by one CU is served to another CU OF THE
-// SAME XCD from the L2 -- the read half of the round trip can stay on chip.  Here ONE persistent launch does both
+// it is a WRITE-BACK cache -- up to ~2 MB of dirty lines per XCD stay in it, a larger footprint streams its stores
+// through -- and a line stored by one CU is served to another CU OF THE SAME XCD from the L2 (sc1 loads): the read
+// half of the round trip can stay on chip, and with one 2 MB buffer of Y per team part of the write half too (the
+// shipped two-buffer form cycles 4 MB through a 4 MB L2: all of Y is written back once and about two thirds of
+// its reads miss, see NBUF below).  Here ONE persistent launch does both
 // steps: the 32 workgroups that share an XCD (one per CU, found by HW_REG_XCC_ID: correctness never rests on a
 // block -> XCD guess) form a team that owns one round of FR = 262144 / N frames at a time, 2 MB of Y, double
 // buffered in the team's 4 MB L2.  Inside a workgroup the sixteen wavefronts split into two ROLES that run their
@@ -305,8 +309,10 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_rows_kernel(const cf* __restr
 //                             transforms, |X|^2 into f64 register accumulators that live for the whole launch.
 // The counters are touched only by atomics that execute in the XCD's L2.  Every spin is bounded; a team that does
 // not assemble (a CU busy with someone else's kernel, an unexpected XCD population) raises ctl->abort, everybody
-// leaves, and K3's companion kernel NaN-fills the spectrum -- loud, never wrong.  The engine proves the path once
-// at creation and otherwise keeps K2a/K2b.
+// leaves, K3 is told to skip (its d_skip word is ctl->abort) and K3's companion kernel reports the launch to the
+// host (and NaN-fills a caller-owned spectrum) -- the engine then runs the same bytes through K2a/K2b and keeps
+// to them (rpf_engine.cpp, recover_fused): loud, never wrong, and never a lost acquisition on the queue path.
+// The engine proves the path once at creation and otherwise keeps K2a/K2b.
 struct FusedCtl {
     unsigned arrivals[8][32];     // [xcd][0]: members registered (own 128-byte line each)
     // One pair of counters per buffer, cumulative over the rounds that use the buffer: a producer arrives for round j only
@@ -918,12 +924,32 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
     }
 }
 
-// K3 companion: if the fused kernel gave up, the spectrum must not look like one.
-__global__ void fused_poison_kernel(const FusedCtl* __restrict__ ctl, double* __restrict__ out, int N)
+// K3 companion: what became of the fused launch (launch_fused_verdict).
+__global__ void fused_verdict_kernel(const FusedCtl* __restrict__ ctl, double* __restrict__ out, int N,
+                                     unsigned* __restrict__ verdict, unsigned* __restrict__ aborts)
 {
     if (ctl->abort[0] == 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (verdict) *verdict = 1u;
+        if (aborts) *aborts += 1u;               // (launches of one engine are stream-ordered: one writer at a time)
+    }
+    if (out == nullptr) return;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
         out[i] = __builtin_nan("");
+}
+
+// Test double of "a CU held by someone else's kernel" (launch_fourstep_fused, fault = 2): one wavefront that owns
+// 96 KB of LDS -- no fused workgroup fits beside it -- until the fused launch has raised its abort flag (or ~20 s).
+__global__ __launch_bounds__(64) void fused_squatter_kernel(const FusedCtl* __restrict__ ctl, unsigned* __restrict__ running)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char squat[];
+    if (threadIdx.x == 0) {
+        squat[0] = 1;
+        __hip_atomic_store(running, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long t0 = wall_clock64();
+        while (l2_read_scalar(&ctl->abort[0]) == 0 && wall_clock64() - t0 < 2000000000ull)      // 100 MHz: 20 s
+            __builtin_amdgcn_s_sleep(32);
+    }
 }
 
 #ifdef RPF_FUSED_PROFILE
@@ -1293,15 +1319,36 @@ hipError_t fourstep_fused_prepare(int N, int device, int* grid)
 }
 
 // Frames [0, nframes) -> d_partial[8 * FR][N] (overwritten).  d_ctl: fourstep_fused_ctl_bytes() of
-// device memory; d_scratch: fourstep_fused_scratch_bytes(N).  Follow K3 with launch_fused_poison.
+// device memory; d_scratch: fourstep_fused_scratch_bytes(N).  Follow K3 (d_skip = fourstep_fused_abort_word) with launch_fused_verdict.
 hipError_t launch_fourstep_fused(int N, bool window, bool use_dma, const uint8_t* d_stream, long nframes,
                                  const cf* d_tw_n1, const cf* d_tw_n2, const cf* d_twN, const float* d_window,
-                                 cf* d_scratch, double* d_partial, void* d_ctl, hipStream_t stream)
+                                 cf* d_scratch, double* d_partial, void* d_ctl, hipStream_t stream, int fault)
 {
     const SplitInfo* s = find_split(N);
     if (!s || nframes < 1 || nframes > 0x7fffffffL) return hipErrorInvalidValue;
     hipError_t err = hipMemsetAsync(d_ctl, 0, sizeof(FusedCtl), stream);
     if (err != hipSuccess) return err;
+    if (fault == 1) {
+        // (tests) a 33rd arrival on XCD 0: the teams are not eight times 32, every workgroup leaves at once
+        err = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&static_cast<FusedCtl*>(d_ctl)->arrivals[0][0]), 1, 1, stream);
+        if (err != hipSuccess) return err;
+    } else if (fault == 2) {
+        // (tests) one CU is taken before the launch: 255 workgroups register, the 256th cannot start, the spins run out.
+        // The squatter leaves when it sees this launch's abort flag, so the flag must be clear before it starts.
+        static hipStream_t squat_stream = nullptr;
+        static unsigned* running = nullptr;
+        if ((err = hipStreamSynchronize(stream)) != hipSuccess) return err;
+        if (!squat_stream && (err = hipStreamCreateWithFlags(&squat_stream, hipStreamNonBlocking)) != hipSuccess) return err;
+        if (!running && (err = hipHostMalloc(reinterpret_cast<void**>(&running), 64, hipHostMallocMapped)) != hipSuccess) return err;
+        *running = 0;
+        constexpr int kSquatLds = 96 * 1024;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_squatter_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kSquatLds);
+        hipLaunchKernelGGL(fused_squatter_kernel, dim3(1), dim3(64), kSquatLds, squat_stream,
+                           static_cast<const FusedCtl*>(d_ctl), running);
+        if ((err = hipGetLastError()) != hipSuccess) return err;
+        for (int i = 0; i < 2000000 && __atomic_load_n(running, __ATOMIC_ACQUIRE) == 0; ++i) std::this_thread::yield();
+    }
     FusedFn fn = s->fused[window ? 1 : 0][use_dma ? 1 : 0];
 #ifdef RPF_FUSED_PROFILE
     if (const char* mode = getenv("RPF_FUSED_MODE"); mode && !window && use_dma) {
@@ -1333,9 +1380,12 @@ hipError_t launch_fourstep_fused(int N, bool window, bool use_dma, const uint8_t
     }
 }
 
-hipError_t launch_fused_poison(const void* d_ctl, double* d_out, int N, hipStream_t stream)
+const unsigned* fourstep_fused_abort_word(const void* d_ctl) { return &static_cast<const FusedCtl*>(d_ctl)->abort[0]; }
+
+hipError_t launch_fused_verdict(const void* d_ctl, double* d_out, int N, unsigned* verdict, unsigned* aborts, hipStream_t stream)
 {
-    hipLaunchKernelGGL(fused_poison_kernel, dim3(64), dim3(256), 0, stream, static_cast<const FusedCtl*>(d_ctl), d_out, N);
+    hipLaunchKernelGGL(fused_verdict_kernel, dim3(d_out ? 64 : 1), dim3(256), 0, stream, static_cast<const FusedCtl*>(d_ctl),
+                       d_out, N, verdict, aborts);
     return hipGetLastError();
 }
 

@@ -46,11 +46,15 @@ hipError_t launch_fft_accum_hops(int N, int vid, bool window, bool use_dma, cons
 // d_out[bin] = (accumulate ? d_out[bin] : 0) + sum_{s < nslots} d_partial[s*stride + bin],
 // summed in a fixed order (deterministic).
 // slot_stride = distance between partial spectra in elements (0: N).  N even.
+// d_skip (may be null): a device word read when the kernel runs; non-zero = leave d_out untouched (the partial
+// spectra are not a result: fourstep_fused_abort_word).
 hipError_t launch_reduce(const double* d_partial, int nslots, int N, double* d_out,
-                         bool accumulate, hipStream_t stream, bool partial_f32 = false, size_t slot_stride = 0);
+                         bool accumulate, hipStream_t stream, bool partial_f32 = false, size_t slot_stride = 0,
+                         const unsigned* d_skip = nullptr);
 // The same for H hops in one launch: d_out[h*N + bin] from the slots [slots.begin[h], slots.begin[h+1]).
 hipError_t launch_reduce_hops(const double* d_partial, const SlotRanges& slots, int H, int N, double* d_out,
-                              bool accumulate, hipStream_t stream, bool partial_f32 = false, size_t slot_stride = 0);
+                              bool accumulate, hipStream_t stream, bool partial_f32 = false, size_t slot_stride = 0,
+                              const unsigned* d_skip = nullptr);
 
 // ---- mixed-radix path (KM, rpf_mixed.hip): the planned kernel for the sizes of mixed_plans.inc, its split form
 // for those of mixed_plans_split.inc (the two tables are the list of sizes), the run-time Stockham kernel for every
@@ -93,11 +97,18 @@ int fourstep_fused_slots(int N);              // partial spectra written: 8 team
 size_t fourstep_fused_ctl_bytes();
 // fails (hipErrorInvalidValue) unless the device has 256 CUs and one workgroup fits a CU
 hipError_t fourstep_fused_prepare(int N, int device, int* grid);
+// fault (tests only, rpf_debug_fused_fault): 1 = the launch finds 33 workgroups on XCD 0 (gives up at once);
+// 2 = a squatter workgroup holds one CU's LDS until the launch has given up (the real failure: ~0.5 - 5 s)
 hipError_t launch_fourstep_fused(int N, bool window, bool use_dma, const uint8_t* d_stream, long nframes,
                                  const cf* d_tw_n1, const cf* d_tw_n2, const cf* d_twN, const float* d_window,
-                                 cf* d_scratch, double* d_partial, void* d_ctl, hipStream_t stream);
-// after K3: NaN-fills d_out if the fused kernel raised its abort flag (team did not assemble)
-hipError_t launch_fused_poison(const void* d_ctl, double* d_out, int N, hipStream_t stream);
+                                 cf* d_scratch, double* d_partial, void* d_ctl, hipStream_t stream, int fault = 0);
+// The launch's abort flag as a device word (K3's d_skip): valid from the launch until the next one on the same d_ctl.
+const unsigned* fourstep_fused_abort_word(const void* d_ctl);
+// After K3: what became of the fused launch.  If it raised its abort flag (teams did not assemble): *verdict = 1 and
+// ++*aborts (words the host can read: pinned, mapped), and d_out (may be null: K3 was told to skip) is NaN-filled
+// -- what a launch that gave up leaves must not look like a spectrum.
+hipError_t launch_fused_verdict(const void* d_ctl, double* d_out, int N, unsigned* verdict, unsigned* aborts,
+                                hipStream_t stream);
 hipError_t fourstep_fused_aborted(const void* d_ctl, hipStream_t stream, bool* aborted);
 
 // ---- large Bluestein path (rpf_fourstep.hip): even N in (4096, 131072], not a power of two --

@@ -850,14 +850,17 @@ __global__ __launch_bounds__(WG, OCC) void bluestein_kernel(const uint8_t* __res
 // range, in a fixed order (bit-reproducible for a given grid): thread (g, b) sums the slots
 // g, g+GROUPS, g+2 GROUPS, ... of the bin pair b -- 16-byte loads, UNROLL of them in flight -- then
 // the GROUPS group sums are added in group order.  blockIdx.y = hop.
+// skip (may be null): a device word; non-zero = the partial spectra are not a result (the fused four-step
+// kernel gave up) and `out` is left as it is.
 template <typename PT, int PAIRS, int GROUPS, int UNROLL>
 __global__ __launch_bounds__(PAIRS* GROUPS) void reduce_kernel(
     const PT* __restrict__ partial, const SlotRanges slots, int N, double* __restrict__ out,
-    int accumulate, size_t stride)
+    int accumulate, size_t stride, const unsigned* __restrict__ skip)
 {
     typedef PT pt2 __attribute__((ext_vector_type(2)));
     typedef double d2 __attribute__((ext_vector_type(2)));
     __shared__ d2 red[GROUPS][PAIRS + 1];
+    if (skip != nullptr && *skip != 0) return;
     const int hop = blockIdx.y;
     const int first = slots.begin[hop], nslots = slots.begin[hop + 1] - first;
     const int b = threadIdx.x % PAIRS, g = threadIdx.x / PAIRS;
@@ -1166,22 +1169,23 @@ hipError_t launch_bluestein(int N, const uint8_t* d_stream, long nframes, const 
 namespace {
 template <typename PT, int PAIRS, int GROUPS, int UNROLL>
 void launch_reduce_shape(const PT* d_partial, const SlotRanges& slots, int H, int N, double* d_out, bool accumulate,
-                         hipStream_t stream, size_t stride)
+                         hipStream_t stream, size_t stride, const unsigned* d_skip = nullptr)
 {
     const dim3 blocks((N + 2 * PAIRS - 1) / (2 * PAIRS), H);
     hipLaunchKernelGGL((reduce_kernel<PT, PAIRS, GROUPS, UNROLL>), blocks, dim3(PAIRS * GROUPS), 0, stream, d_partial,
-                       slots, N, d_out, accumulate ? 1 : 0, stride);
+                       slots, N, d_out, accumulate ? 1 : 0, stride, d_skip);
 }
 }  // namespace
 
 hipError_t launch_reduce_hops(const double* d_partial, const SlotRanges& slots, int H, int N, double* d_out,
-                              bool accumulate, hipStream_t stream, bool partial_f32, size_t slot_stride)
+                              bool accumulate, hipStream_t stream, bool partial_f32, size_t slot_stride,
+                              const unsigned* d_skip)
 {
     if (H < 1 || H > kMaxHops) return hipErrorInvalidValue;
     const size_t stride = slot_stride ? slot_stride : static_cast<size_t>(N);
     if (partial_f32) {
         launch_reduce_shape<float, 8, 32, 8>(reinterpret_cast<const float*>(d_partial), slots, H, N, d_out, accumulate,
-                                             stream, stride);
+                                             stream, stride, d_skip);
         return hipGetLastError();
     }
     int shape = 0;
@@ -1196,18 +1200,19 @@ hipError_t launch_reduce_hops(const double* d_partial, const SlotRanges& slots, 
     case 4: launch_reduce_shape<double, 8, 16, 16>(d_partial, slots, H, N, d_out, accumulate, stream, stride); break;
     case 5: launch_reduce_shape<double, 32, 8, 8>(d_partial, slots, H, N, d_out, accumulate, stream, stride); break;
     case 6: launch_reduce_shape<double, 16, 32, 8>(d_partial, slots, H, N, d_out, accumulate, stream, stride); break;
-    default: launch_reduce_shape<double, 8, 16, 8>(d_partial, slots, H, N, d_out, accumulate, stream, stride); break;
+    default: launch_reduce_shape<double, 8, 16, 8>(d_partial, slots, H, N, d_out, accumulate, stream, stride, d_skip); break;
     }
     return hipGetLastError();
 }
 
 hipError_t launch_reduce(const double* d_partial, int nslots, int N, double* d_out,
-                         bool accumulate, hipStream_t stream, bool partial_f32, size_t slot_stride)
+                         bool accumulate, hipStream_t stream, bool partial_f32, size_t slot_stride,
+                         const unsigned* d_skip)
 {
     SlotRanges one;
     one.begin[0] = 0;
     for (int h = 1; h <= kMaxHops; ++h) one.begin[h] = nslots;
-    return launch_reduce_hops(d_partial, one, 1, N, d_out, accumulate, stream, partial_f32, slot_stride);
+    return launch_reduce_hops(d_partial, one, 1, N, d_out, accumulate, stream, partial_f32, slot_stride, d_skip);
 }
 
 void make_twiddles(int N, std::vector<cf>& out)

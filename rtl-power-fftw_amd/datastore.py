@@ -185,6 +185,19 @@ class Datastore:
     def max_hops_per_launch(self):
         return self._lib.rpf_max_hops_per_launch()
 
+    def fused_status(self):
+        """rpf_fused_status: is the fused four-step kernel what the next launch runs, how many of its launches gave
+        up, how many of those the queue worker ran again on the two-kernel path."""
+        active = ctypes.c_int()
+        gave_up, recovered = ctypes.c_int64(), ctypes.c_int64()
+        self._check(self._lib.rpf_fused_status(self._handle, ctypes.byref(active), ctypes.byref(gave_up),
+                                               ctypes.byref(recovered)))
+        return {"active": bool(active.value), "gave_up": gave_up.value, "recovered": recovered.value}
+
+    def debug_fused_fault(self, mode, skip=0, count=-1):
+        """rpf_debug_fused_fault (test hook)."""
+        self._check(self._lib.rpf_debug_fused_fault(self._handle, mode, skip, count))
+
     def launch_info(self):
         vals = [ctypes.c_int() for _ in range(4)]
         self._check(self._lib.rpf_last_launch_info(self._handle, *[ctypes.byref(v) for v in vals]))

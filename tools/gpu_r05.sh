@@ -27,6 +27,11 @@ ranks)
     python3 -c "import json;d=json.load(open('$OUT/c5_shard_as${n}_rccl.json'));print('shard-as $n + 1-rank RCCL reduce: ms_per_step', d['ms_per_step'])"
   done
   ;;
+fused)
+  timeout 900 python -m pytest tests/test_gpu_fused_abort.py -m gpu -x -q -rs > $OUT/fused_pytest.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/fused_pytest.log
+  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "four_step or fused" > $OUT/fused_parity.log 2>&1; echo "parity rc=$?"; tail -5 $OUT/fused_parity.log
+  for f in 0 8; do timeout 300 python bench.py --workload C4 --engine-flags $f --no-cpu-baseline --no-end-to-end > $OUT/bench_c4_flags$f.json 2>/dev/null; python3 -c "import json;d=json.load(open('$OUT/bench_c4_flags$f.json'));print('C4 engine-flags $f:', d['value']/1e9, 'Gsample/s', d['ms_per_step'], 'ms', 'kernel', d['roofline']['kernel_ms'], d['roofline']['kernel'][:40])"; done
+  ;;
 final)
   shift; bash tools/gpu_final_check.sh "$@"
   ;;
