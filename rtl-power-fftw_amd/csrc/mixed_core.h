@@ -22,6 +22,7 @@
 #pragma once
 
 #include "dft_small.h"
+#include "dft_small_wide.h"
 
 namespace rpf {
 
@@ -33,9 +34,13 @@ struct MPass {
 // TW: where a thread's twiddles live -- 0 registers; 1 per-thread rows of an LDS table; 2 registers for pass 0
 // (every thread's are different) and, for the later passes, one LDS table per pass indexed by [k][ntail] (threads
 // with the same ntail share an entry: (R_i - 1) S_i entries, a few percent of N).
+// TW + 4 (kWideLast): the LAST pass runs in double (dft_small_wide.h, mix_last_pass_accumulate) -- the pass in which a
+// float32 transform of a tone-rich frame loses its accuracy; the split / paired forms' plans carry it.
+constexpr int kWideLast = 4;
 template <int N_, int FPW_, int TW_, class... Ps>
 struct MixPlan {
-    static constexpr int N = N_, FPW = FPW_, TW = TW_;
+    static constexpr int N = N_, FPW = FPW_, TW = TW_ & 3;
+    static constexpr bool WIDE = (TW_ & kWideLast) != 0;
     static constexpr int F = sizeof...(Ps);
     static constexpr int Rs[F] = {Ps::R...};
     static constexpr int Gs[F] = {Ps::G...};
@@ -106,6 +111,32 @@ struct MixPlan {
     }
     static_assert(valid(), "radices must multiply to N and R_i G_i must divide N");
 };
+
+// The same plan with the wide last pass (kWideLast).
+template <class PL>
+struct WidePlanOf;
+template <int N_, int FPW_, int TW_, class... Ps>
+struct WidePlanOf<MixPlan<N_, FPW_, TW_, Ps...>> {
+    using type = MixPlan<N_, FPW_, TW_ | kWideLast, Ps...>;
+};
+template <class PL>
+using WidePlan = typename WidePlanOf<PL>::type;
+
+// The split / paired forms of 40000 bins and more run their M-point plan with the WIDE last pass (mixed_core.h: the last
+// butterfly and the squares in double): from there on a float32 last pass beside a strong line leaves less than 15 % of
+// the parity bar against the CPU path on at least one of the recorded tone streams (profiles/r04_fullsize_errors.json:
+// 8.3e-7 ... 9.96e-7 from 42000 bins up), and so do four smaller sizes (8.0 ... 8.6e-7).  Below, the float pass keeps
+// >= 20 % and its speed (the wide pass costs 7 % in the median and up to 2 x where its 4 R_last registers spill).
+// DESIGN.md 6; RPF_SPLIT_WIDE=0 (make nowide): every form on the float pass, for A/B.
+#ifndef RPF_SPLIT_WIDE
+#define RPF_SPLIT_WIDE 1
+#endif
+constexpr bool split_is_wide(int n)
+{
+    return RPF_SPLIT_WIDE != 0 && (n >= 40000 || n == 21000 || n == 32000 || n == 34000 || n == 35000);
+}
+template <int P, class PL>
+using SplitPlan = std::conditional_t<split_is_wide(P * PL::N), WidePlan<PL>, PL>;
 
 // slot of register 0 of butterfly g of thread t in pass I, and the constant added for register n
 template <class PL, int I>
@@ -260,6 +291,26 @@ RPF_HD void mix_butterfly(cf* v, const cf* tw)
     if constexpr (I < PL::F - 1) {
 #pragma unroll
         for (int k = 1; k < R; ++k) v[k] = cmul(v[k], tw[k - 1]);
+    }
+}
+
+// The last pass of butterfly v (R_last values fetched from the slab) and pwr += |X|^2 (datastore.cxx:83-85) into the
+// butterfly's R_last accumulators.  Float plans: the float butterfly, squares folded in as in phase_accumulate.
+// Wide plans: the values go to double first, the butterfly and the squares are double arithmetic.
+template <class PL>
+RPF_HD void mix_last_pass_accumulate(cf* v, double* acc)
+{
+    constexpr int R = PL::RLAST;
+    if constexpr (PL::WIDE) {
+        cd w[R];
+#pragma unroll
+        for (int n = 0; n < R; ++n) w[n] = cd{static_cast<double>(v[n].x), static_cast<double>(v[n].y)};
+        WideDft<R>::run(w);
+#pragma unroll
+        for (int k = 0; k < R; ++k) acc[k] = __builtin_fma(w[k].y, w[k].y, __builtin_fma(w[k].x, w[k].x, acc[k]));
+    } else {
+        mix_butterfly<PL, PL::F - 1>(v, nullptr);
+        phase_accumulate(v, acc, R);
     }
 }
 

@@ -98,8 +98,12 @@ __device__ __forceinline__ void plan_later_passes(int t, cf* slab, const cf* tw,
                 cf v[R];
                 mix_fetch<PL, I>(sb, v, slab);
                 if constexpr (last) {
-                    mix_butterfly<PL, I>(v, nullptr);
-                    if (active) phase_accumulate(v, acc + g * R, R);
+                    if constexpr (PL::WIDE) {
+                        if (active) mix_last_pass_accumulate<PL>(v, acc + g * R);
+                    } else {
+                        mix_butterfly<PL, I>(v, nullptr);
+                        if (active) phase_accumulate(v, acc + g * R, R);
+                    }
                 } else {
                     if constexpr (PL::TW == 0) {
                         mix_butterfly<PL, I>(v, tw + PL::tw_offset(I) + g * (R - 1));
@@ -490,7 +494,7 @@ constexpr int split_window_mode()
 template <int P, class PL, int WM, bool ROLL = false>
 constexpr PlanForm split_form()
 {
-    return {mixed_split_kernel<PL, P, WM, ROLL>, PL::WG, 1, PL::LDS_BYTES + (WM == 3 ? 4 * P * PL::N : 0), P};
+    return {mixed_split_kernel<SplitPlan<P, PL>, P, WM, ROLL>, PL::WG, 1, PL::LDS_BYTES + (WM == 3 ? 4 * P * PL::N : 0), P};
 }
 template <class PL>
 constexpr PlanEntry plan_entry(int variant)

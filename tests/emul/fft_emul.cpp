@@ -185,11 +185,11 @@ void mixed_passes(std::vector<std::vector<cf>>& tws, std::vector<cf>& slab, cons
                 } else {
                     rpf::mix_fetch<PL, I>(rpf::mix_slot_base<PL, I>(t, g), v, slab.data());
                 }
-                rpf::mix_butterfly<PL, I>(v, tws[t].data() + PL::tw_offset(I) + g * (R - 1));
                 if constexpr (I < PL::F - 1) {
+                    rpf::mix_butterfly<PL, I>(v, tws[t].data() + PL::tw_offset(I) + g * (R - 1));
                     rpf::mix_store<PL, I>(rpf::mix_slot_base<PL, I>(t, g), v, slab.data());
                 } else {
-                    rpf::phase_accumulate(v, acc[t].data() + g * R, R);
+                    rpf::mix_last_pass_accumulate<PL>(v, acc[t].data() + g * R);       // (float, or double for the wide plans)
                 }
             }
         mixed_passes<PL, I + 1>(tws, slab, frame, window, acc);
@@ -371,7 +371,7 @@ constexpr ShippedPlan plan_entry(int)
 template <int SPLIT, class PL, int WM = 0, bool ROLL = false>
 constexpr ShippedPlan split_entry(int)
 {
-    return {SPLIT * PL::N, &run_mixed_split<PL, SPLIT>};
+    return {SPLIT * PL::N, &run_mixed_split<rpf::SplitPlan<SPLIT, PL>, SPLIT>};      // (float or wide last pass: mixed_core.h)
 }
 template <int R, int G = 1>
 using P = MPass<R, G>;

@@ -132,8 +132,9 @@ def test_shipped_mixed_radix_plans_are_well_formed():
             seen.add(n)
             assert lib.rpf_supported_n(n) == 1, n
     assert len(seen) >= 199 and {500, 1000, 7000, 10000, 14000, 16384, 20000, 32768, 50000, 60000, 80000, 96000} <= seen
-    # (round 4 took ten split-form sizes out: tests/test_gpu_heldout.py)
-    assert not ({52000, 64000, 72000, 75000, 76000, 77000, 90000, 98304, 100000, 105000} & seen)
+    # (round 4 took ten split-form sizes out; round 5 put them back on the plans they had, with the last pass in double:
+    #  tests/test_gpu_heldout.py decides whether they stay)
+    assert {52000, 64000, 72000, 75000, 76000, 77000, 90000, 98304, 100000, 105000} <= seen and len(seen) >= 209
     # the per-size overrides (find_form takes the first match): sizes of the tables, each (size, run) once, split form
     text = open(os.path.join(ROOT, "rtl-power-fftw_amd", "csrc", "mixed_plans_override.inc")).read()
     keys = re.findall(r"^\s+\{(\d+), (true|false), split_form<(\d+), ", text, flags=re.M)

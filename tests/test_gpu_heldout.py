@@ -13,7 +13,13 @@ the five of FLOAT32_LIMIT below, where the CPU path itself is ~1e-6 or more from
 of their own that says what is asserted instead.
 
 Round 4's outcome: ten split-form sizes failed and left the table (52000, 64000, 72000, 75000, 76000, 77000, 90000,
-98304, 100000, 105000); the first seven pass here on large Bluestein, the last three are in FLOAT32_LIMIT.
+98304, 100000, 105000); the first seven passed here on large Bluestein, the last three are in FLOAT32_LIMIT.
+
+Round 5: tools/analysis/parity_passes.cpp found where the split / paired forms lose their accuracy -- the LAST pass, in
+which a line's energy has collected in one butterfly and every float32 rounding inside it lands on the weak bins beside
+the line -- and the forms of 40000 bins and more run that pass in double now (mixed_core.h, split_is_wide).  The ten
+sizes are back in the table ON THE PLANS THEY HAD; a THIRD held-out stream (held_out_c, a new constant below) was
+added after the change.  Same rule: what fails here leaves.
 
 The errors are written to the file $RPF_PARITY_RECORD names (tools/gpu_final_check.sh sets it ->
 profiles/r04_fullsize_errors.json), else to pytest's tmp_path: running the tests has no side effect on the tree."""
@@ -33,21 +39,27 @@ pytestmark = pytest.mark.gpu
 HELD_OUT_KEY = 0x52304F34_48454C44
 
 
+HELD_OUT_KEY_C = 0x52303543_54484952      # round 5's third stream
+
+
 def held_out_seeds(N):
     a = (HELD_OUT_KEY ^ (N * 0x9E3779B97F4A7C15)) & 0x7FFFFFFF
     b = ((HELD_OUT_KEY >> 17) + 7919 * N * N + 104729) & 0x7FFFFFFF
-    return [("held_out_a", a), ("held_out_b", b)]
+    c = ((HELD_OUT_KEY_C * (2 * N + 1)) ^ (HELD_OUT_KEY_C >> 29) ^ (N << 7)) & 0x7FFFFFFF
+    return [("held_out_a", a), ("held_out_b", b), ("held_out_c", c)]
 
 
 # Sizes at which float32 itself gives out on these streams: the CPU path -- the reference's own arithmetic -- sits 0.9e-6
 # ... 2.2e-6 from float64 truth in its worst bin (deterministic lines 1e4 above the weakest bins, 17 - 19 butterfly stages),
 # so two correct float32 transforms differ by more than 1e-6 per bin whoever computes them.  Measured on the held-out
 # streams (profiles/r04_heldout_alternatives.txt): no kernel this library has -- split form, large Bluestein, four-step
-# fused or two-kernel -- holds the plain bar AGAINST the CPU path there.  They get the limit test below instead; 98304,
-# 100000 and 105000 left the split-form table for large Bluestein, the one closest to the truth.
-FLOAT32_LIMIT = {98304: 1e-6, 100000: 1e-6, 105000: 1e-6, 262144: 3e-6, 524288: 3e-6}     # N -> bound on |gpu - truth| / truth
+# fused or two-kernel -- holds the plain bar AGAINST the CPU path there.  They get the limit test below instead.
+# 131072 joined them in round 5: on its four held-out cases the CPU path is 1.05 - 1.49e-6 from the truth (the GPU
+# 0.97 - 1.60e-6) -- it held the plain bar against the CPU path in round 4 with no margin (9.0e-7), by the luck of two
+# streams.  From 98304 bins up, on tone-rich input, "<= 1e-6 against the CPU path" is not a property of float32.
+FLOAT32_LIMIT = {98304: 1e-6, 100000: 1e-6, 105000: 1e-6, 131072: 2.5e-6, 262144: 3e-6, 524288: 3e-6}     # N -> bound on |gpu - truth| / truth
 
-# every size a picker chose a plan for, in any round: today's table and the seven sizes that left it for large Bluestein
+# every size a picker chose a plan for, in any round (the seven sizes that spent round 4 on large Bluestein included)
 PICKED_SIZES = sorted(set(n for n in THIN_MARGIN_SIZES if n not in FLOAT32_LIMIT) | {52000, 64000, 72000, 75000, 76000, 77000, 90000})
 
 
@@ -80,8 +92,8 @@ def errors_on(N, seed, torch_dev, R=64):
 @pytest.mark.parametrize("N", PICKED_SIZES)
 def test_picked_sizes_hold_the_bar_on_streams_no_picker_has_seen(N, torch_dev, tmp_path):
     """64 frames of the noise + tones stream (deterministic lines 1e4 above the weakest bins: a float32 FFT's
-    rounding error is coherent there and does not average down), rectangular and Hann, on two held-out seeds, at
-    every split-form / paired-form size and the two largest four-step powers of two: GPU against the CPU path."""
+    rounding error is coherent there and does not average down), rectangular and Hann, on three held-out seeds, at
+    every split-form / paired-form size and 16384 / 32768: GPU against the CPU path."""
     failures = []
     for name, seed in held_out_seeds(N):
         out = errors_on(N, seed, torch_dev)
@@ -101,7 +113,7 @@ def test_where_float32_gives_out(N, torch_dev, tmp_path):
     distance from the CPU path is what it is between two float32 transforms there -- measured 0.6 - 2.0e-6, recorded, and
     held to 2.5e-6 as a sanity bound; on the bins where the CPU path is itself within 5e-7 of the truth (>= 99.9 % of
     them) it is recorded too (measured 4.1e-7 - 1.06e-6)."""
-    for name, seed in held_out_seeds(N)[: 1 if N > 262144 else 2]:
+    for name, seed in held_out_seeds(N)[: 1 if N > 262144 else 3]:
         stream = rpf.synth.noise_tones_iq(seed, N * 64)
         for windowed in ((False,) if N > 262144 else (False, True)):
             w = rpf.synth.hann_window(N) if windowed else None

@@ -32,6 +32,20 @@ fused)
   timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "four_step or fused" > $OUT/fused_parity.log 2>&1; echo "parity rc=$?"; tail -5 $OUT/fused_parity.log
   for f in 0 8; do timeout 300 python bench.py --workload C4 --engine-flags $f --no-cpu-baseline --no-end-to-end > $OUT/bench_c4_flags$f.json 2>/dev/null; python3 -c "import json;d=json.load(open('$OUT/bench_c4_flags$f.json'));print('C4 engine-flags $f:', d['value']/1e9, 'Gsample/s', d['ms_per_step'], 'ms', 'kernel', d['roofline']['kernel_ms'], d['roofline']['kernel'][:40])"; done
   ;;
+wide)
+  # the split / paired forms with the wide (double) last pass against their float32 last pass: rate of every size, then
+  # the held-out and tone-stream parity of the shipped (wide) build
+  SPLIT="${SPLIT:-21000 32000 34000 35000 40000 42000 44000 45000 46000 48000 49000 50000 51000 52000 54000 55000 56000 57000 60000 63000 64000 65000 66000 68000 69000 70000 72000 75000 76000 77000 78000 80000 81000 81920 88000 90000 92000 96000 98304 100000 104000 105000 108000}"
+  CASES=$(for n in $SPLIT; do echo -n "$n:0 "; done)
+  SWEEP_K=100 timeout 900 python tools/gpu_sweep.py $CASES > $OUT/sweep_wide.txt 2>&1; echo "sweep wide rc=$?"
+  RPF_ENGINE_LIB=$ROOT/rtl-power-fftw_amd/librpf_engine_nowide.so SWEEP_K=100 timeout 900 python tools/gpu_sweep.py $CASES > $OUT/sweep_nowide.txt 2>&1; echo "sweep nowide rc=$?"
+  rm -f $OUT/heldout_wide.json
+  RPF_PARITY_RECORD=$OUT/heldout_wide.json timeout 2400 python -m pytest tests/test_gpu_heldout.py tests/test_gpu_parity.py -m gpu -q -k "held or picked or float32 or thin or split or mixed" > $OUT/heldout_wide.log 2>&1; echo "heldout rc=$?"; tail -15 $OUT/heldout_wide.log
+  ;;
+stream)
+  tools/h2d_rate > $OUT/h2d_rate.txt 2>&1; echo "h2d_rate rc=$?"; cat $OUT/h2d_rate.txt
+  LD_LIBRARY_PATH=$ROOT/rtl-power-fftw_amd tools/queue_rate > $OUT/queue_rate.txt 2>&1; echo "queue_rate rc=$?"; cat $OUT/queue_rate.txt
+  ;;
 final)
   shift; bash tools/gpu_final_check.sh "$@"
   ;;
