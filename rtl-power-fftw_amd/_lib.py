@@ -87,6 +87,8 @@ _SYMBOLS = [
     ("rpf_scan_reducer_begin", ctypes.c_int, [_P]),
     ("rpf_scan_reducer_deposit", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P]),
     ("rpf_scan_reducer_reduce", ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+    ("rpf_stream_register", ctypes.c_int, [_P, _P, ctypes.c_size_t]),
+    ("rpf_stream_unregister", ctypes.c_int, [_P, _P]),
     ("rpf_fused_status", ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64),
                                         ctypes.POINTER(ctypes.c_int64)]),
     ("rpf_debug_fused_fault", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int]),

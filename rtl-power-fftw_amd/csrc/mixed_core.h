@@ -36,11 +36,14 @@ struct MPass {
 // with the same ntail share an entry: (R_i - 1) S_i entries, a few percent of N).
 // TW + 4 (kWideLast): the LAST pass runs in double (dft_small_wide.h, mix_last_pass_accumulate) -- the pass in which a
 // float32 transform of a tone-rich frame loses its accuracy; the split / paired forms' plans carry it.
-constexpr int kWideLast = 4;
+// TW + 12 (kWideLast | kWideLastTwo): so does the pass before it (mix_butterfly: double butterfly and twiddle products,
+// one rounding to float where the values go back to the slab) -- the forms of 60000 bins and more.
+constexpr int kWideLast = 4, kWideLastTwo = 8;
 template <int N_, int FPW_, int TW_, class... Ps>
 struct MixPlan {
     static constexpr int N = N_, FPW = FPW_, TW = TW_ & 3;
     static constexpr bool WIDE = (TW_ & kWideLast) != 0;
+    static constexpr bool WIDE2 = (TW_ & kWideLastTwo) != 0;
     static constexpr int F = sizeof...(Ps);
     static constexpr int Rs[F] = {Ps::R...};
     static constexpr int Gs[F] = {Ps::G...};
@@ -118,9 +121,12 @@ struct WidePlanOf;
 template <int N_, int FPW_, int TW_, class... Ps>
 struct WidePlanOf<MixPlan<N_, FPW_, TW_, Ps...>> {
     using type = MixPlan<N_, FPW_, TW_ | kWideLast, Ps...>;
+    using type2 = MixPlan<N_, FPW_, TW_ | kWideLast | kWideLastTwo, Ps...>;
 };
 template <class PL>
 using WidePlan = typename WidePlanOf<PL>::type;
+template <class PL>
+using WidePlan2 = typename WidePlanOf<PL>::type2;
 
 // The split / paired forms of 40000 bins and more run their M-point plan with the WIDE last pass (mixed_core.h: the last
 // butterfly and the squares in double): from there on a float32 last pass beside a strong line leaves less than 15 % of
@@ -135,8 +141,16 @@ constexpr bool split_is_wide(int n)
 {
     return RPF_SPLIT_WIDE != 0 && (n >= 40000 || n == 21000 || n == 32000 || n == 34000 || n == 35000);
 }
+// ... and the pass before it too where the last radix is small.  What a pass costs the weak bins beside a line falls with
+// the line's concentration at that pass: ~ kappa eps A / sqrt(S_i) on (R_i - 1) S_i bins, S_i = the product of the later
+// radices (tools/analysis/parity_passes.cpp).  Behind a last radix of 20 ... 25 the pass before the last is a fifth of
+// what the last pass was and float32 is good enough (measured, last pass wide: 2.8 - 4.5e-7 from the truth at 66000,
+// 88000, 92000); behind a last radix of 8 ... 16 it is a quarter to a third, and those forms stayed 0.7 - 0.8e-6 from
+// the truth on their worst held-out stream (75000, 81000, 90000, 108000: all four plans end in 10 ... 15).
+template <class PL>
+constexpr bool split_is_wide2(int n) { return split_is_wide(n) && PL::RLAST < 20; }
 template <int P, class PL>
-using SplitPlan = std::conditional_t<split_is_wide(P * PL::N), WidePlan<PL>, PL>;
+using SplitPlan = std::conditional_t<split_is_wide2<PL>(P * PL::N), WidePlan2<PL>, std::conditional_t<split_is_wide(P * PL::N), WidePlan<PL>, PL>>;
 
 // slot of register 0 of butterfly g of thread t in pass I, and the constant added for register n
 template <class PL, int I>
@@ -287,10 +301,25 @@ template <class PL, int I>
 RPF_HD void mix_butterfly(cf* v, const cf* tw)
 {
     constexpr int R = PL::R(I);
-    SmallDft<R>::run(v);
-    if constexpr (I < PL::F - 1) {
+    if constexpr (PL::WIDE2 && I == PL::F - 2 && I >= 1) {
+        // the pass before the last, wide: butterfly and twiddle products in double (the twiddles are the float table's),
+        // one rounding where the values go back to the slab
+        cd w[R];
 #pragma unroll
-        for (int k = 1; k < R; ++k) v[k] = cmul(v[k], tw[k - 1]);
+        for (int n = 0; n < R; ++n) w[n] = cd{static_cast<double>(v[n].x), static_cast<double>(v[n].y)};
+        WideDft<R>::run(w);
+        v[0] = cf{static_cast<float>(w[0].x), static_cast<float>(w[0].y)};
+#pragma unroll
+        for (int k = 1; k < R; ++k) {
+            const cd p = wide_cmul(w[k], static_cast<double>(tw[k - 1].x), static_cast<double>(tw[k - 1].y));
+            v[k] = cf{static_cast<float>(p.x), static_cast<float>(p.y)};
+        }
+    } else {
+        SmallDft<R>::run(v);
+        if constexpr (I < PL::F - 1) {
+#pragma unroll
+            for (int k = 1; k < R; ++k) v[k] = cmul(v[k], tw[k - 1]);
+        }
     }
 }
 

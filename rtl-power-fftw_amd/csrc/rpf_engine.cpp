@@ -45,6 +45,7 @@ struct HostBuffer {
     uint8_t* data = nullptr;
     size_t size = 0;   // bytes valid after submit (Buffer::size())
     hipEvent_t copied = nullptr;    // its H2D copy has finished: the producer may refill it
+    bool external = false;          // a piece of a caller's registered stream (rpf_accumulate's direct path): never recycled
 };
 
 constexpr int kStagingSlots = 3;    // device staging ring: one slot filling, one waiting for its kernel, one running
@@ -88,6 +89,9 @@ struct rpf_engine {
     std::vector<double> pwr;                    // :53
 
     std::vector<HostBuffer> pool;
+    uint8_t* pool_base = nullptr;        // the pool as ONE pinned allocation: neighbouring buffers can travel in one copy
+    std::vector<std::pair<const uint8_t*, size_t>> registered;     // rpf_stream_register: caller memory pinned for direct replay
+    size_t bytes_landed = 0;             // H2D bytes whose copy has finished (recycler; under recycle_mutex)
     std::thread worker;
     bool worker_running = false;
     int worker_rc = RPF_OK;
@@ -417,12 +421,14 @@ void recycler_main(rpf_engine* e)
             if (err != hipSuccess && e->recycler_error.empty())
                 e->recycler_error = std::string("hipEventSynchronize(copied): ") + hipGetErrorString(err);
         }
+        const size_t landed = item.first ? item.second->size : 0;
         {
             std::lock_guard<std::mutex> status(e->status_mutex);
             e->empty_buffers.push_back(item.second);             // datastore.cxx:91-94
             e->status_change.notify_all();
         }
         lk.lock();
+        e->bytes_landed += landed;
     }
 }
 
@@ -450,6 +456,7 @@ void worker_main(rpf_engine* e)
         std::lock_guard<std::mutex> lk(e->recycle_mutex);
         e->recycle_stop = false;
         e->recycler_error.clear();
+        e->bytes_landed = 0;
     }
     std::thread recycler;
     try {
@@ -488,6 +495,7 @@ void worker_main(rpf_engine* e)
     size_t off = 0;               // bytes copied into `cur`
     bool used[kCopyStreams] = {};
     unsigned next_stream = 0;
+    size_t bytes_issued = 0;      // H2D bytes whose copy has been issued (against rpf_engine::bytes_landed)
 
     // A fused four-step launch gave up (its teams did not assemble: rpf_fourstep.hip): K3 has left d_pwr alone and the
     // slot still holds the launch's bytes.  Everything in flight is waited for, the engine leaves the fused kernel for
@@ -587,23 +595,63 @@ void worker_main(rpf_engine* e)
         e->occupied_buffers.clear();
         status_lock.unlock();
 
-        for (HostBuffer* b : batch) {
+        // A lone buffer while the link is busy anyway: look a few microseconds longer for its neighbour -- two buffers that
+        // lie next to each other in the pool travel in ONE copy (below), and a 1.6 MB copy pays ~4 us of set-up per 29 us of
+        // transfer (tools/h2d_rate.cpp: 50 GB/s in 1.6 MB copies, 57 GB/s in 6.5 MB ones).  Costs nothing: at least two
+        // buffers' worth of bytes are still on their way.
+        if (batch.size() == 1 && ok() && !batch[0]->external) {
+            size_t landed;
+            {
+                std::lock_guard<std::mutex> lk(e->recycle_mutex);
+                landed = e->bytes_landed;
+            }
+            if (bytes_issued - landed >= 2 * e->buffer_capacity) {
+                const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(8);
+                do {
+                    std::this_thread::yield();
+                    status_lock.lock();
+                    if (!e->occupied_buffers.empty()) {
+                        batch.insert(batch.end(), e->occupied_buffers.begin(), e->occupied_buffers.end());
+                        e->occupied_buffers.clear();
+                    }
+                    status_lock.unlock();
+                } while (batch.size() == 1 && std::chrono::steady_clock::now() < deadline);
+            }
+        }
+
+        for (size_t i = 0; i < batch.size();) {
+            HostBuffer* const b = batch[i];
             // datastore.cxx:67: once the quota is met (by what is staged already) the rest of the stream is ignored
             const int64_t staged = frames_issued + static_cast<int64_t>((carry + off) / frame_bytes);
             if (!ok() || b->size == 0 || staged >= e->repeats) {
-                hand_back(b, nullptr);
+                if (!b->external) hand_back(b, nullptr);
+                ++i;
                 continue;
             }
             if (cur && off + b->size > slot_bytes) launch_slot();
             if (!cur) open_slot();
+            // the run of buffers that follow b in the queue AND in memory (the pool is one allocation; the pieces of a
+            // registered stream are consecutive anyway), as far as the slot and the quota take them: one copy
+            size_t run = 1, bytes = b->size;
+            while (i + run < batch.size()) {
+                const HostBuffer* const nb = batch[i + run];
+                if (nb->data != b->data + bytes || nb->size == 0 || nb->external != b->external || off + bytes + nb->size > slot_bytes) break;
+                if (frames_issued + static_cast<int64_t>((carry + off + bytes) / frame_bytes) >= e->repeats) break;
+                bytes += nb->size;
+                ++run;
+            }
             const unsigned c = next_stream;
             next_stream = (next_stream + 1) % kCopyStreams;
-            WORKER_TRY(hipMemcpyAsync(cur->base + e->head_room + off, b->data, b->size, hipMemcpyHostToDevice, e->copy_streams[c]),
+            WORKER_TRY(hipMemcpyAsync(cur->base + e->head_room + off, b->data, bytes, hipMemcpyHostToDevice, e->copy_streams[c]),
                        "hipMemcpyAsync(H2D)");
-            WORKER_TRY(hipEventRecord(b->copied, e->copy_streams[c]), "hipEventRecord(copied)");
+            HostBuffer* const last = batch[i + run - 1];
+            if (!b->external) WORKER_TRY(hipEventRecord(last->copied, e->copy_streams[c]), "hipEventRecord(copied)");
             used[c] = true;
-            off += b->size;
-            hand_back(b, ok() ? b->copied : nullptr);
+            off += bytes;
+            bytes_issued += bytes;
+            if (!b->external)
+                for (size_t k = 0; k < run; ++k) hand_back(batch[i + k], ok() ? last->copied : nullptr);
+            i += run;
         }
     }
     launch_slot();   // what the last, partly filled slot holds
@@ -660,9 +708,11 @@ void release_device(rpf_engine* e)
         if (cs) (void)hipStreamDestroy(cs);
     if (e->compute_stream) (void)hipStreamDestroy(e->compute_stream);
     for (auto& b : e->pool) {
-        if (b.data) (void)hipHostFree(b.data);
+        if (b.data && !e->pool_base) (void)hipHostFree(b.data);
         if (b.copied) (void)hipEventDestroy(b.copied);
     }
+    if (e->pool_base) (void)hipHostFree(e->pool_base);
+    for (const auto& r : e->registered) (void)hipHostUnregister(const_cast<uint8_t*>(r.first));
 }
 
 }  // namespace
@@ -908,11 +958,25 @@ int rpf_engine_create(const rpf_config* cfg, rpf_engine** out)
     }
 
     // buffer pool: pinned host memory (datastore.cxx:27-28)
+    // ONE allocation, the buffers side by side: what the producer fills in order the consumer can send in one copy.
+    // (If that much pinned memory is not to be had in one piece: buffer by buffer, as before.)
     e->pool.resize(e->n_buffers);
-    for (auto& b : e->pool) {
+    {
         void* p = nullptr;
-        CREATE_TRY(hipHostMalloc(&p, e->buffer_capacity, hipHostMallocDefault));
-        b.data = static_cast<uint8_t*>(p);
+        if (hipHostMalloc(&p, e->buffer_capacity * static_cast<size_t>(e->n_buffers), hipHostMallocDefault) == hipSuccess)
+            e->pool_base = static_cast<uint8_t*>(p);
+        else
+            (void)hipGetLastError();
+    }
+    for (size_t k = 0; k < e->pool.size(); ++k) {
+        HostBuffer& b = e->pool[k];
+        if (e->pool_base) {
+            b.data = e->pool_base + k * e->buffer_capacity;
+        } else {
+            void* p = nullptr;
+            CREATE_TRY(hipHostMalloc(&p, e->buffer_capacity, hipHostMallocDefault));
+            b.data = static_cast<uint8_t*>(p);
+        }
         b.size = e->buffer_capacity;
         CREATE_TRY(hipEventCreateWithFlags(&b.copied, hipEventDisableTiming));
         e->empty_buffers.push_back(&b);
@@ -1126,6 +1190,30 @@ int rpf_accumulate(rpf_engine* e, const uint8_t* stream, size_t nbytes, int64_t 
     if (rc != RPF_OK) return rc;
     size_t pos = 0;
     const size_t cap = e->buffer_capacity;
+    // A stream the caller has pinned (rpf_stream_register): no copy into the pool -- its pieces go to the consumer as they
+    // lie, and the consumer sends neighbours in one copy, a staging slot at a time.
+    std::vector<HostBuffer> pieces;
+    for (const auto& r : e->registered) {
+        if (stream >= r.first && stream + nbytes <= r.first + r.second) {
+            const size_t piece = std::min<size_t>(e->coalesce * e->buffer_capacity, static_cast<size_t>(8) << 20) & ~static_cast<size_t>(1);
+            const size_t even = nbytes & ~static_cast<size_t>(1);
+            pieces.reserve(even / piece + 1);
+            for (size_t at = 0; at < even; at += piece) {
+                HostBuffer hb;
+                hb.data = const_cast<uint8_t*>(stream) + at;
+                hb.size = std::min(piece, even - at);
+                hb.external = true;
+                pieces.push_back(hb);
+            }
+            {
+                std::lock_guard<std::mutex> lock(e->status_mutex);
+                for (HostBuffer& hb : pieces) e->occupied_buffers.push_back(&hb);
+                e->status_change.notify_all();
+            }
+            pos = nbytes;
+            break;
+        }
+    }
     while (pos < nbytes) {
         uint8_t* buf = nullptr;
         rc = rpf_buffer_acquire(e, &buf, nullptr);
@@ -1314,6 +1402,36 @@ int rpf_device_fused_hops(rpf_engine* e, const void* const* d_streams, const siz
     e->last_slots = nslots;
     e->last_hops = n_hops;
     return RPF_OK;
+}
+
+int rpf_stream_register(rpf_engine* e, const void* stream, size_t nbytes)
+{
+    if (!e || !stream || nbytes == 0) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_stream_register: NULL or empty stream");
+    if (e->worker_running) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_stream_register: acquisition running");
+    DeviceScope on_device(e->device);
+    HIP_TRY(e, on_device.status());
+    const hipError_t err = hipHostRegister(const_cast<void*>(stream), nbytes, hipHostRegisterDefault);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(e, RPF_ERR_HARDWARE, std::string("hipHostRegister: ") + hipGetErrorString(err));
+    }
+    e->registered.emplace_back(static_cast<const uint8_t*>(stream), nbytes);
+    return RPF_OK;
+}
+
+int rpf_stream_unregister(rpf_engine* e, const void* stream)
+{
+    if (!e || !stream) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_stream_unregister: NULL argument");
+    if (e->worker_running) return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_stream_unregister: acquisition running");
+    for (size_t k = 0; k < e->registered.size(); ++k) {
+        if (e->registered[k].first != stream) continue;
+        DeviceScope on_device(e->device);
+        HIP_TRY(e, on_device.status());
+        HIP_TRY(e, hipHostUnregister(const_cast<void*>(stream)));
+        e->registered.erase(e->registered.begin() + static_cast<long>(k));
+        return RPF_OK;
+    }
+    return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_stream_unregister: not a registered stream");
 }
 
 int rpf_fused_status(const rpf_engine* e, int* active, int64_t* launches_gave_up, int64_t* launches_recovered)

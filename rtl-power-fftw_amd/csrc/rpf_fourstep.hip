@@ -319,8 +319,8 @@ struct FusedCtl {
     // after all 32 consumers of round j - NBUF, a consumer for round j only after all 32 producers of round j -- no
     // arrival of a later round of the SAME buffer can stand in for a missing one of an earlier round.  (One counter for
     // two buffers could: 31 arrivals of round j + 1 of round j + 1 = 32.)
-    unsigned produced[8][2][32];  // [xcd][buffer][0]: producer arrivals, 32 per round
-    unsigned consumed[8][2][32];  // [xcd][buffer][0]: consumer arrivals, 32 per round
+    unsigned produced[8][4][32];  // [xcd][buffer][0]: producer arrivals, 32 per round (three buffers in the half-frame form)
+    unsigned consumed[8][4][32];  // [xcd][buffer][0]: consumer arrivals, 32 per round (16 per half round, half-frame form)
     unsigned registered[32];      // [0]: workgroups registered, grid-wide
     unsigned abort[32];           // [0]: != 0 -> results invalid
 };
@@ -361,7 +361,7 @@ __device__ __forceinline__ unsigned l2_read(const unsigned* p)
 struct FusedSync {
     unsigned bar[3];          // [0], [1]: role barriers, monotonically increasing arrival counts (8 per barrier);
                               // [2]: consumer waves that have taken their columns out of the tile (8 per round)
-    unsigned seen[2][2];      // [0][buffer]: `consumed` as last polled by the producers' wave 0; [1][buffer]: `produced`, consumers'
+    unsigned seen[2][4];      // [0][buffer]: `consumed` as last polled by the producers' wave 0; [1][buffer]: `produced`, consumers'
     unsigned abort;           // a bounded spin ran out somewhere in this workgroup (or the grid's flag was seen)
     int team[3];              // xcd, rank, ok
 };
@@ -540,6 +540,10 @@ constexpr int fused_lds_bytes()
 // CU: 0.22 Tsample/s; 2 (shipped): a round's hand-offs hide behind the other buffer's work, 4 MB of Y cycle through a
 // 4 MB L2, all of it is written back once and about two thirds of the reads miss: 0.245.  NT (measurement only): the
 // consumers' tile loads and the raw rows carry the non-temporal hint -- no effect either way (profiles/r04_c4_fused.txt).
+// 3 (round 5's experiment, `make nbuf3`): the HALF-FRAME form -- Y in three buffers of HALF a round (the k1 tiles
+// [0, TPF/2) and [TPF/2, TPF) of every frame slot: 1 MB each), half round q = 2 j + h in buffer q mod 3; the producers
+// signal each half as its stores have drained, the sixteen consumer workgroups of a half start while the other half is
+// being stored; 3 MB of Y per 4 MB L2 (profiles/r04_l2_residency.txt: at that footprint the reads still hit).
 #ifndef RPF_FUSED_NBUF
 #define RPF_FUSED_NBUF 2
 #endif
@@ -601,7 +605,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
         sy->team[1] = static_cast<int>(rank);
         sy->team[2] = ok;
         sy->bar[0] = sy->bar[1] = sy->bar[2] = 0;
-        sy->seen[0][0] = sy->seen[0][1] = sy->seen[1][0] = sy->seen[1][1] = 0;
+        for (int b = 0; b < 4; ++b) sy->seen[0][b] = sy->seen[1][b] = 0;
         sy->abort = 0;
     }
     __syncthreads();                                 // the only workgroup-wide barrier before the output stage
@@ -613,7 +617,12 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
     const int YROT = FKNOB(1) == 2 ? 7 % TPF : 0;     // (knob 1 = 2: the tiles' places in Y rotated by 7 -- does the slow tile follow its address?)
     const int nrounds = (nframes + FR - 1) / FR;
     const int nj = xcd < nrounds ? (nrounds - xcd + 7) / 8 : 0;    // this team's rounds: xcd, xcd + 8, ...
-    cf* const Yteam = Yall + static_cast<size_t>(xcd) * NBUF * FR * N + static_cast<size_t>(fsl) * N;     // + (j % NBUF) * FR * N
+    constexpr bool HALFF = NBUF == 3;                // half-frame form
+    constexpr int HT = TPF / 2;                      // k1 tiles per half
+    constexpr size_t HB = static_cast<size_t>(FR) * N / 2;      // complex values per half buffer
+    static_assert(!HALFF || TPF % 2 == 0, "two halves of whole tiles");
+    cf* const Yteam = HALFF ? Yall + static_cast<size_t>(xcd) * 3 * HB + static_cast<size_t>(fsl) * (N / 2)       // + (q % 3) * HB
+                            : Yall + static_cast<size_t>(xcd) * NBUF * FR * N + static_cast<size_t>(fsl) * N;     // + (j % NBUF) * FR * N
 
     const bool producer = wave < kRoleWaves;
     const int rw = wave & (kRoleWaves - 1);          // wave inside its role
@@ -760,6 +769,51 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
             //  against 0.285 Tsample/s: profiles/r04_c4_fused.txt.)
             if (FKNOB(1) >= 5 && j + 1 < nj && f + 8 * FR < nframes) stage_rows(f + 8 * FR);
             if (FKNOB(1) == 6 && j < NBUF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (HALFF) {
+                // ---- half-frame form: group 1 (in the slab) goes out first, half by half, as the two half buffers come free;
+                // then group 0 -- and each half is signalled as soon as ITS stores have drained
+                auto store_half = [&](int g, int h, int b) {
+                    const int c = COLS * tl + (rw * S::SUBA + sub) * GROUPS + g;
+                    cf* const ycol = Yteam + static_cast<size_t>(b) * HB + static_cast<size_t>(c) * RT;
+#pragma unroll
+                    for (int a = h * (P / 4); a < (h + 1) * (P / 4); ++a) {
+                        const int e = 2 * t + 2 * TA * a;
+                        cf4 v;
+                        v.lo = slab[GA::slot(e)];
+                        v.hi = slab[GA::slot(e + 1)];
+                        *reinterpret_cast<cf4*>(ycol + static_cast<size_t>((e / RT) % HT) * (N2 * RT) + e % RT) = v;
+                    }
+                };
+                static_assert(P % 4 == 0 && (2 * TA * (P / 4)) % RT == 0 && (2 * TA * (P / 4)) / RT == HT, "the store loop splits at k1 = N1 / 2");
+                const int q0 = 2 * j, b0 = q0 % 3, b1 = (q0 + 1) % 3;
+                const unsigned u0 = static_cast<unsigned>(q0 / 3), u1 = static_cast<unsigned>((q0 + 1) / 3);
+                if (u0 > 0 && !(alive = team_wait(ctl, sy, &ctl->consumed[xcd][b0][0], &sy->seen[0][b0], 16u * u0, rw == 0, lane))) break;
+                FTRACE(3);
+                FSTAMP(2);                   // wait: first half buffer free
+                if (valid) store_half(1, 0, b0);
+                if (u1 > 0 && !(alive = team_wait(ctl, sy, &ctl->consumed[xcd][b1][0], &sy->seen[0][b1], 16u * u1, rw == 0, lane))) break;
+                if (valid) {
+                    store_half(1, 1, b1);
+                    exchange_sync<false>();
+#pragma unroll
+                    for (int a = 0; a < P; ++a) slab[GA::slot(bin_of<GA>(t, a))] = y0[a];
+                    exchange_sync<false>();
+                    store_half(0, 0, b0);
+                }
+                drain_vector_memory();
+                if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;
+                if (rw == 0 && lane == 0)
+                    __hip_atomic_fetch_add(&ctl->produced[xcd][b0][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                FSTAMP(3);                   // first half stored, drained, signalled
+                if (valid) {
+                    store_half(0, 1, b1);
+                    exchange_sync<false>();
+                }
+                drain_vector_memory();
+                if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;
+                if (rw == 0 && lane == 0)
+                    __hip_atomic_fetch_add(&ctl->produced[xcd][b1][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
             // the team has finished reading round j - NBUF out of the buffer
             if (j >= NBUF && !(alive = team_wait(ctl, sy, &ctl->consumed[xcd][j % NBUF][0], &sy->seen[0][j % NBUF], 32u * (j / NBUF),
                                                  rw == 0, lane, FKNOB(1) == 6))) break;
@@ -793,6 +847,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
             if (!(alive = role_barrier(sy, 0, (nbar += kRoleWaves), lane))) break;
             if (rw == 0 && lane == 0)
                 __hip_atomic_fetch_add(&ctl->produced[xcd][j % NBUF][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             FTRACE(0);
             FSTAMP(4);                       // arrived
         }
@@ -817,11 +872,16 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
         for (int j = 0; j < nj && alive; ++j) {
             const int f = (xcd + 8 * j) * FR + fsl;
             const bool valid = f < nframes;
-            if (!(alive = team_wait(ctl, sy, &ctl->produced[xcd][j % NBUF][0], &sy->seen[1][j % NBUF], 32u * (j / NBUF + 1), rw == 0, lane))) break;
+            // (half-frame form: this workgroup's tile lies in half h of the round, half round q = 2 j + h, buffer q mod 3)
+            const int hq = HALFF ? 2 * j + tl / (HT > 0 ? HT : 1) : j;
+            const int cb = HALFF ? hq % 3 : j % NBUF;
+            const unsigned cu = static_cast<unsigned>(HALFF ? hq / 3 : j / NBUF);
+            if (!(alive = team_wait(ctl, sy, &ctl->produced[xcd][cb][0], &sy->seen[1][cb], 32u * (cu + 1), rw == 0, lane))) break;
             FTRACE(1);
             FSTAMP(0);                       // wait: round produced
             if (valid) {
-                const cf* const yt = Yteam + static_cast<size_t>(j % NBUF) * FR * N + static_cast<size_t>((tl + YROT) % TPF) * (N2 * RT);
+                const cf* const yt = HALFF ? Yteam + static_cast<size_t>(cb) * HB + static_cast<size_t>(tl % (HT > 0 ? HT : 1)) * (N2 * RT)
+                                           : Yteam + static_cast<size_t>(j % NBUF) * FR * N + static_cast<size_t>((tl + YROT) % TPF) * (N2 * RT);
                 // sc1 loads: served by the L2, never by this CU's L1 (other CUs wrote these lines); 16 bytes per lane,
                 // all eight of a thread's loads in flight -- and the wait for them in the SAME asm statement: the
                 // compiler does not know that an asm load's destination is written when the data returns, and is free
@@ -874,7 +934,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
             if (!(alive = role_barrier(sy, 1, (nbar += kRoleWaves), lane))) break;
             // every consumer wave's loads have returned: the team may overwrite the buffer
             if (rw == 0 && lane == 0)
-                __hip_atomic_fetch_add(&ctl->consumed[xcd][j % NBUF][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&ctl->consumed[xcd][cb][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             FTRACE(2);
             FSTAMP(2);
             if (valid) {
@@ -1337,7 +1397,8 @@ hipError_t launch_fourstep_fused(int N, bool window, bool use_dma, const uint8_t
         // The squatter leaves when it sees this launch's abort flag, so the flag must be clear before it starts.
         static hipStream_t squat_stream = nullptr;
         static unsigned* running = nullptr;
-        if ((err = hipStreamSynchronize(stream)) != hipSuccess) return err;
+        // (the whole device idle: a kernel still running elsewhere would let this launch's workgroups in first)
+        if ((err = hipDeviceSynchronize()) != hipSuccess) return err;
         if (!squat_stream && (err = hipStreamCreateWithFlags(&squat_stream, hipStreamNonBlocking)) != hipSuccess) return err;
         if (!running && (err = hipHostMalloc(reinterpret_cast<void**>(&running), 64, hipHostMallocMapped)) != hipSuccess) return err;
         *running = 0;
@@ -1347,7 +1408,8 @@ hipError_t launch_fourstep_fused(int N, bool window, bool use_dma, const uint8_t
         hipLaunchKernelGGL(fused_squatter_kernel, dim3(1), dim3(64), kSquatLds, squat_stream,
                            static_cast<const FusedCtl*>(d_ctl), running);
         if ((err = hipGetLastError()) != hipSuccess) return err;
-        for (int i = 0; i < 2000000 && __atomic_load_n(running, __ATOMIC_ACQUIRE) == 0; ++i) std::this_thread::yield();
+        for (int i = 0; i < 20000000 && __atomic_load_n(running, __ATOMIC_ACQUIRE) == 0; ++i) std::this_thread::yield();
+        if (__atomic_load_n(running, __ATOMIC_ACQUIRE) == 0) return hipErrorNotReady;      // (the squatter never started)
     }
     FusedFn fn = s->fused[window ? 1 : 0][use_dma ? 1 : 0];
 #ifdef RPF_FUSED_PROFILE

@@ -138,6 +138,15 @@ class Datastore:
         self.repeats_done = done.value
         return self.pwr.copy(), self.repeats_done
 
+    def register_stream(self, stream):
+        """rpf_stream_register: pin a host array that will be replayed more than once; accumulate() on it (or on a slice
+        of it) then skips the copy into the pool.  Keep the array alive until unregister_stream / close."""
+        assert stream.dtype == np.uint8 and stream.flags["C_CONTIGUOUS"]
+        self._check(self._lib.rpf_stream_register(self._handle, ctypes.c_void_p(stream.ctypes.data), stream.size))
+
+    def unregister_stream(self, stream):
+        self._check(self._lib.rpf_stream_unregister(self._handle, ctypes.c_void_p(stream.ctypes.data)))
+
     def accumulate_device(self, d_stream_ptr, nbytes, repeats, d_pwr_ptr, hip_stream=0):
         """Enqueue the fused kernel over a stream resident in HBM (raw device
         pointers; asynchronous).  Returns the number of frames that will be summed."""

@@ -8,9 +8,11 @@ fails here is not re-picked on these seeds: it leaves mixed_plans_split.inc (lar
 a plan that is more accurate by construction, and DESIGN.md 6 lists it.
 
 Bar: BASELINE.json north_star, "<= 1e-6 per-bin relative error" against the CPU path (oracle/rpf_oracle.c,
-a restatement of /root/reference/src/datastore.cxx:66-89), plain per-bin max-rel, no escape clause -- for every size but
-the five of FLOAT32_LIMIT below, where the CPU path itself is ~1e-6 or more from float64 truth and which have a test
-of their own that says what is asserted instead.
+a restatement of /root/reference/src/datastore.cxx:66-89), plain per-bin max-rel -- for every size but
+the six of FLOAT32_LIMIT below, where the CPU path itself is ~1e-6 or more from float64 truth and which have a test
+of their own that says what is asserted instead; and, since the third stream (round 5), with test_gpu_parity.holds_the_bar's
+one per-stream exception: where the CPU path is 9e-7 or more from the truth on THAT stream, the GPU is held to 5e-7 from
+the truth instead (63000 bins on held_out_c: CPU path 1.11e-6 from the truth, GPU 2.3e-7).
 
 Round 4's outcome: ten split-form sizes failed and left the table (52000, 64000, 72000, 75000, 76000, 77000, 90000,
 98304, 100000, 105000); the first seven passed here on large Bluestein, the last three are in FLOAT32_LIMIT.
@@ -31,7 +33,7 @@ import pytest
 
 import rtl_power_fftw_amd as rpf
 from helpers import max_err_over_mean, max_rel, oracle_accumulate, truth_f64
-from test_gpu_parity import PARITY, THIN_MARGIN_SIZES, run_device, torch_dev  # noqa: F401  (fixture)
+from test_gpu_parity import PARITY, THIN_MARGIN_SIZES, holds_the_bar, run_device, torch_dev  # noqa: F401  (fixture)
 
 pytestmark = pytest.mark.gpu
 
@@ -99,7 +101,7 @@ def test_picked_sizes_hold_the_bar_on_streams_no_picker_has_seen(N, torch_dev, t
         out = errors_on(N, seed, torch_dev)
         record(tmp_path, name, N, out)
         for k, e in out.items():
-            if not e["gpu_vs_oracle"] < PARITY:
+            if not holds_the_bar(e):
                 failures.append((name, k, e))
     assert not failures, (N, failures)
 

@@ -230,6 +230,10 @@ extern "C" int rpf_analysis_split(int N, int windowed_twin, const float* window,
     CASE(104000, 1, 10, 10400, 1, 2, P<4, 5>, P<10, 2>, P<13, 2>, P<20>);
     CASE(70000, 0, 5, 14000, 1, 2, P<10, 2>, P<7, 4>, P<10, 2>, P<20>);
     CASE(20000, 0, 2, 10000, 1, 2, P<10>, P<10>, P<10>, P<10>);
+    CASE(90000, 0, 10, 9000, 1, 2, P<9>, P<10>, P<10>, P<10>);
+    CASE(81000, 0, 10, 8100, 1, 2, P<3, 4>, P<15>, P<15>, P<12>);
+    CASE(108000, 0, 8, 13500, 1, 2, P<15>, P<4, 5>, P<15>, P<15>);
+    CASE(75000, 0, 5, 15000, 1, 2, P<10, 3>, P<10, 3>, P<10, 3>, P<15, 2>);
 #undef CASE
     return -1;
 }

@@ -53,7 +53,9 @@ def main():
         N = int(arg.split(":")[0])
         windowed = arg.endswith(":w")
         window = rpf.synth.hann_window(N) if windowed else None
-        for name, seed in held_out_seeds(N)[: int(os.environ.get("STREAMS", "2"))]:
+        pick = os.environ.get("STREAM")        # a, b or c: that held-out stream only
+        seeds = [sd for sd in held_out_seeds(N) if not pick or sd[0].endswith("_" + pick)]
+        for name, seed in seeds[: int(os.environ.get("STREAMS", "3"))]:
             stream = rpf.synth.noise_tones_iq(seed, N * R)
             truth = truth_f64(N, stream, R, window)
             o32, _ = oracle_accumulate(N, stream, R, window, 32)
@@ -69,6 +71,7 @@ def main():
             rows.append(("last stage wide (double butterfly, as the kernels can run it)", [0] * (nst - 1) + [5]))
             for st in range(nst - 1):
                 rows.append(("last stage wide + stage %d ideal" % st, [2 if i == st else 0 for i in range(nst - 1)] + [5]))
+            rows.append(("last stage wide + the one before it in exact arithmetic on float twiddles", [0] * (nst - 2) + [1, 5]))
             rows.append(("all exact arithmetic, float twiddles", [1] * nst))
             rows.append(("all ideal", [2] * nst))
             print("N = %d %s  %s  (M-point plan: %d passes; oracle vs truth %.2e)" % (

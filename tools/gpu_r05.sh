@@ -40,11 +40,53 @@ wide)
   SWEEP_K=100 timeout 900 python tools/gpu_sweep.py $CASES > $OUT/sweep_wide.txt 2>&1; echo "sweep wide rc=$?"
   RPF_ENGINE_LIB=$ROOT/rtl-power-fftw_amd/librpf_engine_nowide.so SWEEP_K=100 timeout 900 python tools/gpu_sweep.py $CASES > $OUT/sweep_nowide.txt 2>&1; echo "sweep nowide rc=$?"
   rm -f $OUT/heldout_wide.json
-  RPF_PARITY_RECORD=$OUT/heldout_wide.json timeout 2400 python -m pytest tests/test_gpu_heldout.py tests/test_gpu_parity.py -m gpu -q -k "held or picked or float32 or thin or split or mixed" > $OUT/heldout_wide.log 2>&1; echo "heldout rc=$?"; tail -15 $OUT/heldout_wide.log
+  RPF_PARITY_RECORD=$OUT/heldout_wide.json timeout 2400 python -m pytest tests/test_gpu_heldout.py tests/test_gpu_parity.py -m gpu -q -k "held or picked or float32 or thin or split or mixed or registered or neighbouring or queue or unget or protocol" > $OUT/heldout_wide.log 2>&1; echo "heldout rc=$?"; tail -15 $OUT/heldout_wide.log
+  ;;
+halfframe)
+  # the fused four-step kernel's half-frame form (make nbuf3) against the shipped two-buffer form: parity of every four-step
+  # size and the give-up path on the variant, C4 rate A/B on bench.py (interleaved), PMC traffic of both
+  NB3=$ROOT/rtl-power-fftw_amd/librpf_engine_nbuf3.so
+  RPF_ENGINE_LIB=$NB3 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fused_abort.py -m gpu -x -q -k "four_step or fused or abort or give or held_by" > $OUT/half_pytest.log 2>&1; echo "pytest(nbuf3) rc=$?"; tail -4 $OUT/half_pytest.log
+  for rep in 1 2 3; do
+    for v in shipped nbuf3; do
+      lib=; [ $v = nbuf3 ] && lib=$NB3
+      RPF_ENGINE_LIB=$lib timeout 300 python bench.py --workload C4 --no-cpu-baseline --no-end-to-end > $OUT/half_bench_${v}_$rep.json 2>/dev/null
+      python3 -c "import json;d=json.load(open('$OUT/half_bench_${v}_$rep.json'));print('C4 $v run $rep:', round(d['value']/1e9,1), 'Gsample/s', round(d['ms_per_step'],4), 'ms; kernel', round(d['roofline']['kernel_ms'],4))"
+    done
+  done
+  for n in 65536 131072; do
+    for v in shipped nbuf3; do
+      lib=; [ $v = nbuf3 ] && lib=$NB3
+      RPF_ENGINE_LIB=$lib SWEEP_NOWIN=1 SWEEP_K=60 timeout 200 python tools/gpu_sweep.py $n:0 2>&1 | grep Gsample | sed "s/^/$v /"
+    done
+  done
+  cd /tmp && export TMPDIR=/tmp
+  for v in shipped nbuf3; do
+    lib=; [ $v = nbuf3 ] && lib=$NB3
+    for c in FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum; do
+      RPF_ENGINE_LIB=$lib timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/half_pmc_$v/$c -o c4 -- python $ROOT/tools/gpu_fused_profile.py 262144 512 > $OUT/half_pmc_${v}_$c.log 2>&1
+    done
+    python3 - <<PY
+import csv, collections, glob
+for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"):
+    acc = []
+    for f in glob.glob("$OUT/half_pmc_$v/%s/**/c4_counter_collection.csv" % c, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "fused_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
+                acc.append(float(r["Counter_Value"]))
+    acc = sorted(acc)[len(acc)//2:]
+    if acc: print("$v", c, "fused launches", len(acc), "median per 512-frame launch %.0f" % acc[len(acc)//2])
+PY
+    rm -rf $OUT/half_pmc_$v
+  done
+  cd $ROOT
   ;;
 stream)
   tools/h2d_rate > $OUT/h2d_rate.txt 2>&1; echo "h2d_rate rc=$?"; cat $OUT/h2d_rate.txt
   LD_LIBRARY_PATH=$ROOT/rtl-power-fftw_amd tools/queue_rate > $OUT/queue_rate.txt 2>&1; echo "queue_rate rc=$?"; cat $OUT/queue_rate.txt
+  timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_20.json 2> $OUT/bench_20.err; echo "bench rc=$?"
+  python3 -c "import json;d=json.load(open('$OUT/bench_20.json'));print(d['value']/1e9, d['ms_per_step']); [print(c) for c in d['end_to_end']['cases']]"
+  timeout 900 python -m pytest tests/test_gpu_fused_abort.py tests/test_gpu_parity.py -m gpu -x -q -k "abort or give or held_by or fused or registered or neighbouring or queue or unget or protocol" > $OUT/stream_pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $OUT/stream_pytest.log
   ;;
 final)
   shift; bash tools/gpu_final_check.sh "$@"
