@@ -605,8 +605,11 @@ void worker_main(rpf_engine* e)
                 std::lock_guard<std::mutex> lk(e->recycle_mutex);
                 landed = e->bytes_landed;
             }
-            if (bytes_issued - landed >= 2 * e->buffer_capacity) {
-                const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(8);
+            const size_t in_flight = bytes_issued - landed;
+            if (in_flight >= 2 * e->buffer_capacity) {
+                // (the more is on its way, the longer the look may take: a buffer's worth is ~30 us of link time)
+                const auto deadline = std::chrono::steady_clock::now() +
+                                      std::chrono::microseconds(in_flight >= 3 * e->buffer_capacity ? 20 : 8);
                 do {
                     std::this_thread::yield();
                     status_lock.lock();

@@ -547,7 +547,7 @@ def test_neighbouring_pool_buffers_travel_in_one_copy_and_nothing_changes():
         assert ds.acquire().ctypes.data % 2 == 0
 
 
-def test_registered_stream_is_replayed_where_it_lies(torch_dev):
+def test_registered_stream_is_replayed_where_it_lies():
     """rpf_stream_register: accumulate() on a pinned caller stream (any part of it) gives what the pool path gives --
     frames straddle the 8 MB pieces --, windowed and not; misuse is refused."""
     N = 4096

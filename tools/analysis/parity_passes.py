@@ -7,6 +7,8 @@ twiddle products compensated, and with everything ideal -- each against float64 
 The held-out streams are named by tests/test_gpu_heldout.py (imported from there: the key is not copied).
 
 usage: parity_passes.py N[:w] ...      (w: the windowed twin under a Hann window)
+       parity_passes.py --radix        the small butterflies' own rounding error, radix by radix: on random inputs, and
+                                       beside a line 100 x the other outputs (what the last pass sees)
 """
 import ctypes
 import os
@@ -46,8 +48,26 @@ def run(lib, N, twin, window, stream, R, mode):
     return pwr, rc
 
 
+def radix_tables(lib):
+    out = (ctypes.c_double * 2)()
+    lib.rpf_analysis_radix_error.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    lib.rpf_analysis_line_exposure.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
+    eps = 2.0 ** -24
+    print("SmallDft<R> (dft_small.h), float32; eps = 2^-24")
+    print(" R   random inputs: rms error / rms output   | one output 100 x the others: rms error on the WEAK outputs, in eps x line")
+    print("                                             |   the butterfly's arithmetic    the rounding of its float inputs")
+    for R in range(2, 26):
+        lib.rpf_analysis_radix_error(R, 20000, out)
+        a = out[0] / eps
+        lib.rpf_analysis_line_exposure(R, 20000, 100.0, out)
+        print("%2d   %.2f eps                                   |   %.3f                          %.3f" % (R, a, out[0], out[1]))
+
+
 def main():
     lib = load()
+    if sys.argv[1:] == ["--radix"]:
+        radix_tables(lib)
+        return
     R = int(os.environ.get("FRAMES", "64"))
     for arg in sys.argv[1:]:
         N = int(arg.split(":")[0])

@@ -88,6 +88,9 @@ stream)
   python3 -c "import json;d=json.load(open('$OUT/bench_20.json'));print(d['value']/1e9, d['ms_per_step']); [print(c) for c in d['end_to_end']['cases']]"
   timeout 900 python -m pytest tests/test_gpu_fused_abort.py tests/test_gpu_parity.py -m gpu -x -q -k "abort or give or held_by or fused or registered or neighbouring or queue or unget or protocol" > $OUT/stream_pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $OUT/stream_pytest.log
   ;;
+tsan)
+  bash tools/gpu_tsan.sh
+  ;;
 final)
   shift; bash tools/gpu_final_check.sh "$@"
   ;;

@@ -24,6 +24,6 @@ SUP
 export TSAN_OPTIONS="halt_on_error=0 exitcode=66 second_deadlock_stack=1 suppressions=$OUT/suppressions.txt"
 echo "== 1. tsan_queue_driver"; timeout 600 tools/tsan_queue_driver > $OUT/driver.log 2>&1; echo "rc=$?"; tail -3 $OUT/driver.log
 echo "== 2. CLI, several engines"; RPF_POWER_CLI=$ROOT/rtl-power-fftw_amd/host/rpf_power_tsan timeout 900 python -m pytest tests/test_host.py -m gpu -x -q -k "several_engines or cli_file_replay" > $OUT/cli.log 2>&1; echo "rc=$?"; tail -3 $OUT/cli.log
-echo "== 3. python queue tests, preloaded runtime"; LD_PRELOAD=$RT RPF_NO_TORCH=1 RPF_ENGINE_LIB=$ROOT/rtl-power-fftw_amd/librpf_engine_tsan.so timeout 900 setarch -R python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "buffer_queue_path or unget_and_early or protocol_errors" > $OUT/pyqueue.log 2>&1; echo "rc=$?"; tail -3 $OUT/pyqueue.log
+echo "== 3. python queue tests, preloaded runtime"; LD_PRELOAD=$RT RPF_NO_TORCH=1 RPF_ENGINE_LIB=$ROOT/rtl-power-fftw_amd/librpf_engine_tsan.so timeout 900 setarch -R python -m pytest tests/test_gpu_parity.py tests/test_gpu_fused_abort.py -m gpu -x -q -k "buffer_queue_path or unget_and_early or protocol_errors or neighbouring or registered or falls_back or one_launch or buffer_protocol" > $OUT/pyqueue.log 2>&1; echo "rc=$?"; tail -3 $OUT/pyqueue.log
 echo "== reports"; grep -c "WARNING: ThreadSanitizer" $OUT/driver.log $OUT/cli.log $OUT/pyqueue.log
 grep -A12 "WARNING: ThreadSanitizer" $OUT/driver.log $OUT/cli.log $OUT/pyqueue.log | head -120
