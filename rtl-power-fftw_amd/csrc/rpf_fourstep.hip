@@ -36,6 +36,7 @@
 #include <cstdlib>
 #include <thread>
 
+#include "dft_small_wide.h"
 #include "fused_layout.h"
 #include "rpf_device_common.h"
 #include "rpf_kernels.h"
@@ -81,6 +82,44 @@ __device__ __forceinline__ void group_fft(int t, cf* x, const cf (&tw)[G::NPASS 
     middle_passes<G, 1>(t, x, tw, slab);
     phase_fetch<G, G::NPASS>(t, x, slab);
     phase_last<G>(x);
+}
+// The row transform's LAST pass, and pwr += |X|^2 from it.  x: the values as fetched for the last pass; acc[a] is register
+// a's bin as after phase_last.  -DRPF_FOURSTEP_WIDE=1 (`make fswide`, NOT shipped): that pass in double, like the split
+// forms' (dft_small_wide.h).  Measured (profiles/r05_fourstep_wide.txt): at 131072 / 262144 bins the GPU then sits
+// 0.58 - 0.84e-6 from float64 truth instead of 1.3 - 2.5e-6, for 2 % of C4's rate -- and 1.5 - 2.3e-6 from the CPU PATH
+// instead of 0.5 - 1.3e-6 (C4's own line bins: 1.59e-6 instead of 4.8e-7): at these power-of-two lengths the CPU path's
+// last passes are the same float32 butterflies as the kernel's and make the same roundings beside a line, so the two
+// agree with each other far better than either agrees with the truth.  north_star's bar is against the CPU path: the
+// shipped kernels keep the float32 pass.
+#ifndef RPF_FOURSTEP_WIDE
+#define RPF_FOURSTEP_WIDE 0
+#endif
+template <class G>
+__device__ __forceinline__ void last_pass_accumulate(cf* x, double* acc)
+{
+    if constexpr (RPF_FOURSTEP_WIDE) {
+        constexpr int R = G::RLAST;
+#pragma unroll
+        for (int g = 0; g < G::P / R; ++g) {
+            cd w[R];
+#pragma unroll
+            for (int n = 0; n < R; ++n) w[n] = cd{static_cast<double>(x[g * R + n].x), static_cast<double>(x[g * R + n].y)};
+            WideDft<R>::run(w);
+#pragma unroll
+            for (int k = 0; k < R; ++k) acc[g * R + k] = __builtin_fma(w[k].y, w[k].y, __builtin_fma(w[k].x, w[k].x, acc[g * R + k]));
+        }
+    } else {
+        phase_last<G>(x);
+        phase_accumulate(x, acc, G::P);
+    }
+}
+// group_fft without its last pass's butterflies: the values as phase_fetch leaves them
+template <class G, bool TWLDS>
+__device__ __forceinline__ void group_fft_but_last(int t, cf* x, const cf (&tw)[G::NPASS - 1][G::P - 1], cf* slab, const cf* twtable)
+{
+    PhaseClock none;
+    middle_passes<G, 1, 0, TWLDS>(t, x, tw, slab, none, twtable);
+    phase_fetch<G, G::NPASS>(t, x, slab);
 }
 // The same with the twiddles of the passes >= 2 read from an LDS table (fill_twlds) instead of held in registers:
 // 2 (P - 1) VGPRs fewer per such pass, which the fused kernel's roles need for their per-lane constants.
@@ -260,8 +299,8 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_rows_kernel(const cf* __restr
         cf x[G::P];
 #pragma unroll
         for (int a = 0; a < G::P; ++a) x[a] = tile[(t + T * a) * S::ROW_PITCH + jrow];
-        group_fft<G>(t, x, tw, slab);
-        phase_accumulate(x, acc, G::P);
+        group_fft_but_last<G, false>(t, x, tw, slab, nullptr);
+        last_pass_accumulate<G>(x, acc);
         exchange_sync<false>();
     }
 
@@ -948,8 +987,8 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                     // next round's tile write waits for all eight arrivals, by then long posted -- a barrier behind the
                     // transforms, where the waves are skewed, cost 1.5 us per round
                     if (g == GROUPS - 1) role_arrive(sy, 2, lane);
-                    if (!FKNOB(2)) group_fft_twlds<GB>(t, x, tw, slab, twtabB);
-                    phase_accumulate(x, acc[g], P);
+                    if (!FKNOB(2)) group_fft_but_last<GB, true>(t, x, tw, slab, twtabB);
+                    last_pass_accumulate<GB>(x, acc[g]);
                     exchange_sync<false>();
                 }
             } else {

@@ -81,6 +81,22 @@ PY
   done
   cd $ROOT
   ;;
+fswide)
+  # the four-step kernels with the last pass of their row transform in double (make fswide) against the shipped float32
+  # pass: errors on the tone streams at 131072 / 262144 and on C4's own stream, C4 rate on bench.py (interleaved)
+  FSW=$ROOT/rtl-power-fftw_amd/librpf_engine_fswide.so
+  for v in shipped fswide; do
+    lib=; [ $v = fswide ] && lib=$FSW
+    RPF_ENGINE_LIB=$lib RPF_PARITY_RECORD=$OUT/fswide_errors_$v.json timeout 900 python -m pytest tests/test_gpu_heldout.py tests/test_gpu_parity.py tests/test_gpu_fullsize.py -m gpu -q -k "float32 or (thin and (131072 or 262144)) or four_step or fused_four or c4" > $OUT/fswide_pytest_$v.log 2>&1; echo "pytest($v) rc=$?"; tail -3 $OUT/fswide_pytest_$v.log
+  done
+  for rep in 1 2 3; do
+    for v in shipped fswide; do
+      lib=; [ $v = fswide ] && lib=$FSW
+      RPF_ENGINE_LIB=$lib timeout 300 python bench.py --workload C4 --no-cpu-baseline --no-end-to-end > $OUT/fswide_bench_${v}_$rep.json 2>/dev/null
+      python3 -c "import json;d=json.load(open('$OUT/fswide_bench_${v}_$rep.json'));print('C4 $v run $rep:', round(d['value']/1e9,1), 'Gsample/s', round(d['ms_per_step'],4), 'ms; kernel', round(d['roofline']['kernel_ms'],4))"
+    done
+  done
+  ;;
 stream)
   tools/h2d_rate > $OUT/h2d_rate.txt 2>&1; echo "h2d_rate rc=$?"; cat $OUT/h2d_rate.txt
   LD_LIBRARY_PATH=$ROOT/rtl-power-fftw_amd tools/queue_rate > $OUT/queue_rate.txt 2>&1; echo "queue_rate rc=$?"; cat $OUT/queue_rate.txt
