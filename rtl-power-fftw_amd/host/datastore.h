@@ -120,6 +120,16 @@ public:
   void finish() {
     check(rpf_finish(engine_, &repeats_done));
     check(rpf_get_power(engine_, pwr.data()));
+    // 65536 ... 262144 bins: a launch of the persistent four-step kernel that could not get the whole device (another
+    // process on it) gives up; the engine has run those bytes through its two-kernel path and keeps to it -- the
+    // acquisition is complete and right, the operator is told once why the rest of the run is a few per cent slower
+    int64_t gave_up = 0;
+    if (rpf_fused_status(engine_, nullptr, &gave_up, nullptr) == RPF_OK && gave_up > fused_gave_up_) {
+      if (fused_gave_up_ == 0)
+        std::cerr << "Note: the device was busy; the FFT worker left its single-launch kernel for the two-kernel path "
+                     "(results are unaffected)." << std::endl;
+      fused_gave_up_ = gave_up;
+    }
   }
   // the engine behind this Datastore (multi-device scans hand it to the scan reducer)
   const rpf_engine* engine() const { return engine_; }
@@ -137,6 +147,7 @@ private:
     if (rc != RPF_OK) throw RPFexception(rpf_last_error(engine_), (ReturnValue)rc);
   }
   rpf_engine* engine_ = nullptr;
+  int64_t fused_gave_up_ = 0;
 };
 
 }  // namespace rpf_host

@@ -73,8 +73,8 @@ def main():
         N = int(arg.split(":")[0])
         windowed = arg.endswith(":w")
         window = rpf.synth.hann_window(N) if windowed else None
-        pick = os.environ.get("STREAM")        # a, b or c: that held-out stream only
-        seeds = [sd for sd in held_out_seeds(N) if not pick or sd[0].endswith("_" + pick)]
+        only_stream = os.environ.get("STREAM")        # a, b or c: that held-out stream only
+        seeds = [sd for sd in held_out_seeds(N) if not only_stream or sd[0].endswith("_" + only_stream)]
         for name, seed in seeds[: int(os.environ.get("STREAMS", "3"))]:
             stream = rpf.synth.noise_tones_iq(seed, N * R)
             truth = truth_f64(N, stream, R, window)
