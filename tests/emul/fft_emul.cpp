@@ -405,6 +405,19 @@ extern "C" int rpf_emul_small_dft(int R, float* v)
     return -1;
 }
 
+// the same through dft_small_wide.h (double; interleaved re, im): the split forms' wide last passes
+extern "C" int rpf_emul_wide_dft(int R, double* v)
+{
+    rpf::cd* c = reinterpret_cast<rpf::cd*>(v);
+    switch (R) {
+#define CASE(r) case r: rpf::WideDft<r>::run(c); return 0
+        CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(7); CASE(8); CASE(9); CASE(10); CASE(11); CASE(12); CASE(13); CASE(14);
+        CASE(15); CASE(16); CASE(17); CASE(18); CASE(19); CASE(20); CASE(21); CASE(22); CASE(23); CASE(24); CASE(25);
+#undef CASE
+    }
+    return -1;
+}
+
 extern "C" int rpf_emul_accumulate(int N, int P, const float* window, const uint8_t* stream,
                                    long nframes, double* pwr)
 {

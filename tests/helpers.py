@@ -121,6 +121,16 @@ def emul_small_dft(x):
     return v[0::2] + 1j * v[1::2]
 
 
+def emul_wide_dft(x):
+    """dft_small_wide.h's double-precision DFT of len(x) points."""
+    v = np.empty(2 * len(x), np.float64)
+    v[0::2], v[1::2] = x.real, x.imag
+    lib = emul_lib()
+    lib.rpf_emul_wide_dft.argtypes = [ctypes.c_int, dp]
+    assert lib.rpf_emul_wide_dft(len(x), v.ctypes.data_as(dp)) == 0
+    return v[0::2] + 1j * v[1::2]
+
+
 def oracle_accumulate(N, stream, repeats, window=None, precision=32):
     stream = np.ascontiguousarray(stream, dtype=np.uint8)
     pwr = np.zeros(N)

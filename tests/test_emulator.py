@@ -70,6 +70,26 @@ def test_small_dft_radices(R):
         assert np.abs(np.delete(got, k)).max() < 2e-6 * R
 
 
+@pytest.mark.parametrize("R", list(range(2, 26)))
+def test_wide_dft_radices(R):
+    """dft_small_wide.h: every radix once more in double (the split forms' wide last passes, round 5) against numpy's
+    double DFT to double precision, natural order in and out like SmallDft -- the accumulators the outputs are folded
+    into are the float pass's, bin for bin."""
+    from helpers import emul_wide_dft
+    rng = np.random.default_rng(100 + R)
+    x = rng.normal(size=R) + 1j * rng.normal(size=R)
+    ref = np.fft.fft(x)
+    assert np.abs(emul_wide_dft(x) - ref).max() < 4e-15 * R * np.abs(ref).max()
+    for k in range(R):
+        tone = np.exp(2j * np.pi * k * np.arange(R) / R)
+        got = emul_wide_dft(tone)
+        assert int(np.argmax(np.abs(got))) == k and abs(got[k] - R) < 1e-13 * R
+        assert np.abs(np.delete(got, k)).max() < 1e-13 * R
+    # the same outputs as the float butterfly, to float precision: the two are interchangeable in a plan
+    xf = x.astype(np.complex64)
+    assert np.abs(emul_small_dft(xf) - emul_wide_dft(xf.astype(np.complex128))).max() < 3e-7 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("plan", range(20))
 @pytest.mark.parametrize("windowed", [False, True])
 def test_emulated_mixed_plan_matches_oracle(plan, windowed):
