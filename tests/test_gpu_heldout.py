@@ -24,7 +24,7 @@ sizes are back in the table ON THE PLANS THEY HAD; a THIRD held-out stream (held
 added after the change.  Same rule: what fails here leaves.
 
 The errors are written to the file $RPF_PARITY_RECORD names (tools/gpu_final_check.sh sets it ->
-profiles/r04_fullsize_errors.json), else to pytest's tmp_path: running the tests has no side effect on the tree."""
+profiles/rNN_fullsize_errors.json, round 5: r05), else to pytest's tmp_path: running the tests has no side effect on the tree."""
 import json
 import os
 

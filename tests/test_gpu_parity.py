@@ -219,7 +219,7 @@ def test_tone_stream_parity_where_the_margin_is_thin(N, torch_dev, tmp_path):
     form's error depends on the stream by up to 3 x, so its sizes are held to the bar on two streams (the second
     is the one tools/gpu_parity_score.py scores plan candidates on as well).  These are the streams the plans were
     PICKED on; the held-out streams are test_gpu_heldout.py's.
-    (The errors are recorded in the file $RPF_PARITY_RECORD names -> profiles/r04_fullsize_errors.json; without it
+    (The errors are recorded in the file $RPF_PARITY_RECORD names -> profiles/rNN_fullsize_errors.json (round 5: r05); without it
     in pytest's tmp_path.)"""
     import json
     R = 64
