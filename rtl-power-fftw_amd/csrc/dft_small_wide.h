@@ -191,4 +191,121 @@ RPF_WIDE_DFT(22, WidePfaDft<22, 2, 11>);
 RPF_WIDE_DFT(24, WidePfaDft<24, 8, 3>);
 #undef RPF_WIDE_DFT
 
+// ---- the wide LAST pass as one piece: float values in, |X|^2 folded into the f64 accumulators, nothing in between kept
+// longer or wider than it has to be.  The kernels that run it are the register-bound ones (nine-wave workgroups, 168
+// VGPRs): a butterfly that converts all R inputs up front and holds R double outputs needs 4 R registers twice over and
+// spills -- and the spills, not the f64 arithmetic, were what the wide pass cost (21000 bins: 117 scratch instructions
+// per thread against 32, 4.7 x the frame's own bytes in scratch traffic).  Here, for a composite R = A B: the level-1
+// butterflies convert their A inputs as they load them, their outputs wait for level 2 as `wide_mid`s, and each level-2
+// butterfly's B outputs go straight into the accumulators.
+// RPF_WIDE_MID_FLOAT=1 (measured, NOT shipped): the values between the two levels as floats -- 2 R registers instead of
+// 4 R, half of the wide pass's extra spills gone and up to 2 x of its cost back (21000: 150 -> 244, 98304: 79 -> 161
+// Gsample/s; median + 5 %) -- but that one more float rounding sits where the line is already concentrated, and three
+// sizes (75000, 88000, 108000) went back over the parity bar on a held-out stream.  Shipped: doubles between the levels.
+#ifndef RPF_WIDE_MID_FLOAT
+#define RPF_WIDE_MID_FLOAT 0
+#endif
+#if RPF_WIDE_MID_FLOAT
+typedef cf wide_mid;
+RPF_HD wide_mid to_mid(cd a) { return cf{static_cast<float>(a.x), static_cast<float>(a.y)}; }
+RPF_HD cd from_mid(wide_mid a) { return cd{static_cast<double>(a.x), static_cast<double>(a.y)}; }
+#else
+typedef cd wide_mid;
+RPF_HD wide_mid to_mid(cd a) { return a; }
+RPF_HD cd from_mid(wide_mid a) { return a; }
+#endif
+RPF_HD cd widen(cf a) { return cd{static_cast<double>(a.x), static_cast<double>(a.y)}; }
+RPF_HD void fold_square(double& acc, cd x) { acc = __builtin_fma(x.y, x.y, __builtin_fma(x.x, x.x, acc)); }
+
+// Out: what becomes of output k -- the last pass folds |X_k|^2 into acc[k]; the pass before it (kWideLastTwo) multiplies
+// by the twiddle and rounds back to float.
+struct WideFold {
+    double* acc;
+    RPF_HD void operator()(int k, cd x) const { fold_square(acc[k], x); }
+};
+struct WideTwiddleStore {
+    cf* out;
+    const cf* tw;          // tw[k - 1] for k >= 1
+    RPF_HD void operator()(int k, cd x) const
+    {
+        if (k > 0) x = wide_cmul(x, static_cast<double>(tw[k - 1].x), static_cast<double>(tw[k - 1].y));
+        out[k] = cf{static_cast<float>(x.x), static_cast<float>(x.y)};
+    }
+};
+
+template <int R, int A, int B, bool PFA>
+struct WideTwoLevel {
+    // level 1, column n2: A inputs converted as they are loaded, A outputs (times W_R^{n2 k1} in the Cooley-Tukey form)
+    template <int N2>
+    static RPF_HD void column(const cf* v, wide_mid* t, std::integral_constant<int, N2>)
+    {
+        if constexpr (N2 < B) {
+            cd u[A];
+#pragma unroll
+            for (int n1 = 0; n1 < A; ++n1) u[n1] = widen(v[PFA ? (B * n1 + A * N2) % R : B * n1 + N2]);
+            WideDft<A>::run(u);
+            store(u, t, std::integral_constant<int, N2>{}, std::integral_constant<int, 0>{});
+            column(v, t, std::integral_constant<int, N2 + 1>{});
+        }
+    }
+    template <int N2, int K1>
+    static RPF_HD void store(const cd* u, wide_mid* t, std::integral_constant<int, N2>, std::integral_constant<int, K1>)
+    {
+        if constexpr (K1 < A) {
+            if constexpr (PFA) t[K1 * B + N2] = to_mid(u[K1]);
+            else t[K1 * B + N2] = to_mid(wide_mul_wconst<R, K1 * N2>(u[K1]));
+            store(u, t, std::integral_constant<int, N2>{}, std::integral_constant<int, K1 + 1>{});
+        }
+    }
+    template <class Out>
+    static RPF_HD void run(const cf* v, const Out& out)
+    {
+        static_assert(R == A * B, "");
+        constexpr int bi = mod_inverse(B % A, A), ai = mod_inverse(A % B, B);
+        wide_mid t[R];
+        column(v, t, std::integral_constant<int, 0>{});
+#pragma unroll
+        for (int k1 = 0; k1 < A; ++k1) {
+            cd w[B];
+#pragma unroll
+            for (int n2 = 0; n2 < B; ++n2) w[n2] = from_mid(t[k1 * B + n2]);
+            WideDft<B>::run(w);
+#pragma unroll
+            for (int k2 = 0; k2 < B; ++k2) out(PFA ? (B * bi * k1 + A * ai * k2) % R : k1 + A * k2, w[k2]);
+        }
+    }
+};
+
+// v[0 .. R): the pass's float inputs (left untouched); out(k, X_k) for every output
+template <int R>
+struct WidePass {
+    template <class Out>
+    static RPF_HD void run(const cf* v, const Out& out)
+    {
+        if constexpr (R == 6) WideTwoLevel<6, 2, 3, true>::run(v, out);
+        else if constexpr (R == 10) WideTwoLevel<10, 2, 5, true>::run(v, out);
+        else if constexpr (R == 12) WideTwoLevel<12, 4, 3, true>::run(v, out);
+        else if constexpr (R == 14) WideTwoLevel<14, 2, 7, true>::run(v, out);
+        else if constexpr (R == 15) WideTwoLevel<15, 3, 5, true>::run(v, out);
+        else if constexpr (R == 18) WideTwoLevel<18, 2, 9, true>::run(v, out);
+        else if constexpr (R == 20) WideTwoLevel<20, 4, 5, true>::run(v, out);
+        else if constexpr (R == 21) WideTwoLevel<21, 3, 7, true>::run(v, out);
+        else if constexpr (R == 22) WideTwoLevel<22, 2, 11, true>::run(v, out);
+        else if constexpr (R == 24) WideTwoLevel<24, 8, 3, true>::run(v, out);
+        else if constexpr (R == 8) WideTwoLevel<8, 4, 2, false>::run(v, out);
+        else if constexpr (R == 9) WideTwoLevel<9, 3, 3, false>::run(v, out);
+        else if constexpr (R == 16) WideTwoLevel<16, 4, 4, false>::run(v, out);
+        else if constexpr (R == 25) WideTwoLevel<25, 5, 5, false>::run(v, out);
+        else {
+            // small radices and the odd primes: one level
+            cd w[R];
+#pragma unroll
+            for (int n = 0; n < R; ++n) w[n] = widen(v[n]);
+            WideDft<R>::run(w);
+#pragma unroll
+            for (int k = 0; k < R; ++k) out(k, w[k]);
+        }
+    }
+};
+
 }  // namespace rpf

@@ -304,16 +304,10 @@ RPF_HD void mix_butterfly(cf* v, const cf* tw)
     if constexpr (PL::WIDE2 && I == PL::F - 2 && I >= 1) {
         // the pass before the last, wide: butterfly and twiddle products in double (the twiddles are the float table's),
         // one rounding where the values go back to the slab
-        cd w[R];
+        cf o[R];
+        WidePass<R>::run(v, WideTwiddleStore{o, tw});
 #pragma unroll
-        for (int n = 0; n < R; ++n) w[n] = cd{static_cast<double>(v[n].x), static_cast<double>(v[n].y)};
-        WideDft<R>::run(w);
-        v[0] = cf{static_cast<float>(w[0].x), static_cast<float>(w[0].y)};
-#pragma unroll
-        for (int k = 1; k < R; ++k) {
-            const cd p = wide_cmul(w[k], static_cast<double>(tw[k - 1].x), static_cast<double>(tw[k - 1].y));
-            v[k] = cf{static_cast<float>(p.x), static_cast<float>(p.y)};
-        }
+        for (int k = 0; k < R; ++k) v[k] = o[k];
     } else {
         SmallDft<R>::run(v);
         if constexpr (I < PL::F - 1) {
@@ -331,12 +325,7 @@ RPF_HD void mix_last_pass_accumulate(cf* v, double* acc)
 {
     constexpr int R = PL::RLAST;
     if constexpr (PL::WIDE) {
-        cd w[R];
-#pragma unroll
-        for (int n = 0; n < R; ++n) w[n] = cd{static_cast<double>(v[n].x), static_cast<double>(v[n].y)};
-        WideDft<R>::run(w);
-#pragma unroll
-        for (int k = 0; k < R; ++k) acc[k] = __builtin_fma(w[k].y, w[k].y, __builtin_fma(w[k].x, w[k].x, acc[k]));
+        WidePass<R>::run(v, WideFold{acc});
     } else {
         mix_butterfly<PL, PL::F - 1>(v, nullptr);
         phase_accumulate(v, acc, R);

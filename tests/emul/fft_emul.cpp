@@ -418,6 +418,23 @@ extern "C" int rpf_emul_wide_dft(int R, double* v)
     return -1;
 }
 
+// the fused wide pass (WidePass: float values in, every output handed to a functor): out[k] = X_k, interleaved re, im
+struct CollectWide {
+    double* out;
+    void operator()(int k, rpf::cd x) const { out[2 * k] = x.x; out[2 * k + 1] = x.y; }
+};
+extern "C" int rpf_emul_wide_pass(int R, const float* v, double* out)
+{
+    const cf* c = reinterpret_cast<const cf*>(v);
+    switch (R) {
+#define CASE(r) case r: rpf::WidePass<r>::run(c, CollectWide{out}); return 0
+        CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(7); CASE(8); CASE(9); CASE(10); CASE(11); CASE(12); CASE(13); CASE(14);
+        CASE(15); CASE(16); CASE(17); CASE(18); CASE(19); CASE(20); CASE(21); CASE(22); CASE(23); CASE(24); CASE(25);
+#undef CASE
+    }
+    return -1;
+}
+
 extern "C" int rpf_emul_accumulate(int N, int P, const float* window, const uint8_t* stream,
                                    long nframes, double* pwr)
 {

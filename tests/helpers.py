@@ -131,6 +131,17 @@ def emul_wide_dft(x):
     return v[0::2] + 1j * v[1::2]
 
 
+def emul_wide_pass(x):
+    """dft_small_wide.h's fused wide pass of len(x) complex64 inputs: the outputs it hands on, as complex128."""
+    v = np.empty(2 * len(x), np.float32)
+    v[0::2], v[1::2] = x.real, x.imag
+    out = np.zeros(2 * len(x), np.float64)
+    lib = emul_lib()
+    lib.rpf_emul_wide_pass.argtypes = [ctypes.c_int, fp, dp]
+    assert lib.rpf_emul_wide_pass(len(x), v.ctypes.data_as(fp), out.ctypes.data_as(dp)) == 0
+    return out[0::2] + 1j * out[1::2]
+
+
 def oracle_accumulate(N, stream, repeats, window=None, precision=32):
     stream = np.ascontiguousarray(stream, dtype=np.uint8)
     pwr = np.zeros(N)

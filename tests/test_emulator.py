@@ -88,6 +88,15 @@ def test_wide_dft_radices(R):
     # the same outputs as the float butterfly, to float precision: the two are interchangeable in a plan
     xf = x.astype(np.complex64)
     assert np.abs(emul_small_dft(xf) - emul_wide_dft(xf.astype(np.complex128))).max() < 3e-7 * np.abs(ref).max()
+    # the fused pass the kernels run (inputs converted as they are loaded, floats between the two levels of a composite
+    # radix, every output handed on under its natural index): the DFT of the float inputs to one float rounding
+    from helpers import emul_wide_pass
+    reff = np.fft.fft(xf.astype(np.complex128))
+    assert np.abs(emul_wide_pass(xf) - reff).max() < 1.5e-7 * np.abs(reff).max()
+    for k in range(R):
+        tone = np.exp(2j * np.pi * k * np.arange(R) / R).astype(np.complex64)
+        got = emul_wide_pass(tone)
+        assert int(np.argmax(np.abs(got))) == k and abs(got[k] - R) < 1e-6 * R and np.abs(np.delete(got, k)).max() < 2e-6 * R
 
 
 @pytest.mark.parametrize("plan", range(20))
