@@ -157,6 +157,13 @@ def cpu_baseline(N, R, stream, pwr_gpu, window=None):
         out["mkl"] = mkl_probe.report(N, stream[: 2 * N * head], head, {"oracle": o_head, "gpu_first_frames": None}, window)
     except Exception as exc:
         out["mkl"] = {"mkl": "probe failed: %r" % (exc,)}
+    # ... and a fourth: pocketfft in single precision (scipy.fft on complex64 input)
+    try:
+        from oracle import pocketfft_probe
+        head = min(R, 400)
+        out["pocketfft"] = pocketfft_probe.report(N, stream[: 2 * N * head], head, {"oracle": o_head}, window)
+    except Exception as exc:
+        out["pocketfft"] = {"pocketfft": "probe failed: %r" % (exc,)}
     return out
 
 

@@ -319,22 +319,6 @@ def test_oracle_against_mkl_the_third_float32_fft():
         assert rep["max_rel_vs_oracle"] < 1e-6, rep
 
 
-def reference_loop_around(fft32, N, stream, R, window=None):
-    """The reference's worker loop (/root/reference/src/datastore.cxx:66-89) around ANY float32 c2c FFT:
-    (v - 127) * (-1)^n [* window] in float, transform, pwr += re^2 + im^2 in double."""
-    x = stream[: 2 * N * R].astype(np.float32).reshape(R, N, 2) - np.float32(127.0)
-    sgn = np.where(np.arange(N) % 2 == 0, np.float32(1.0), np.float32(-1.0))
-    if window is not None:
-        sgn = sgn * window.astype(np.float32)
-    z = (x[:, :, 0] * sgn + 1j * (x[:, :, 1] * sgn)).astype(np.complex64)
-    pwr = np.zeros(N)
-    for f in range(R):
-        X = fft32(z[f])
-        assert X.dtype == np.complex64
-        pwr += X.real.astype(np.float64) ** 2 + X.imag.astype(np.float64) ** 2
-    return pwr
-
-
 @pytest.mark.parametrize("N,R,windowed", [(512, 100, False), (4096, 64, False), (4096, 64, True), (500, 64, False),
                                           (66000, 64, False), (100000, 64, False), (262144, 8, False)])
 def test_oracle_against_pocketfft_in_float32(N, R, windowed):
@@ -345,10 +329,11 @@ def test_oracle_against_pocketfft_in_float32(N, R, windowed):
     pocketfft 0.70 - 0.81e-6 from the truth, the oracle 0.52 - 0.56e-6, the two 0.58 - 0.83e-6 apart: an independent
     float32 FFT says what DESIGN.md 6 says, the bar has no margin left there for anybody).  262144 is a float32-limit size
     (tests/test_gpu_heldout.py): both are ~1.6 - 1.9e-6 from the truth after 8 frames and are only held to 3e-6."""
-    import scipy.fft
+    from oracle import pocketfft_probe              # the reference's loop around scipy.fft in single precision
     stream = rpf.synth.noise_tones_iq(60 + N % 7, N * R)
     w = rpf.synth.hann_window(N) if windowed else None
-    pocket = reference_loop_around(scipy.fft.fft, N, stream, R, w)
+    pocket, frames = pocketfft_probe.accumulate(N, stream, R, w)
+    assert frames == R
     orc, done = oracle_accumulate(N, stream, R, w)
     assert done == R
     truth = truth_f64(N, stream, R, w)
