@@ -77,6 +77,7 @@ def record(tmp_path, name, N, out):
 
 
 def errors_on(N, seed, torch_dev, R=64):
+    from oracle import pocketfft_probe          # recorded, not asserted: a float32 FFT nobody here wrote, as a second comparator
     stream = rpf.synth.noise_tones_iq(seed, N * R)
     out = {}
     for windowed in (False, True):
@@ -86,8 +87,12 @@ def errors_on(N, seed, torch_dev, R=64):
         assert n == R
         o32, _ = oracle_accumulate(N, stream, R, w, 32)
         truth = truth_f64(N, stream, R, w)
-        out["hann" if windowed else "rect"] = {"gpu_vs_oracle": max_rel(got, o32), "gpu_vs_truth": max_rel(got, truth),
-                                                 "oracle_vs_truth": max_rel(o32, truth)}
+        e = {"gpu_vs_oracle": max_rel(got, o32), "gpu_vs_truth": max_rel(got, truth), "oracle_vs_truth": max_rel(o32, truth)}
+        if pocketfft_probe.available():
+            pocket, _ = pocketfft_probe.accumulate(N, stream, R, w)
+            e.update({"gpu_vs_pocketfft": max_rel(got, pocket), "pocketfft_vs_truth": max_rel(pocket, truth),
+                      "oracle_vs_pocketfft": max_rel(o32, pocket)})
+        out["hann" if windowed else "rect"] = e
     return out
 
 
