@@ -312,9 +312,29 @@ def build_parser():
     ap.add_argument("--scans-per-reduce", type=int, default=4,
                     help="C5: scans whose spectra travel in ONE reduce (fewer, larger collectives: the 256 KB of one scan are "
                          "latency-bound; 1 = a reduce per scan)")
+    ap.add_argument("--scans-per-launch", type=int, default=0,
+                    help="C5: consecutive scans whose hops share ONE persistent kernel launch (a scan's hops already do); "
+                         "0 = as many as divide --scans-per-reduce and fit rpf_max_hops_per_launch(); 1 = a launch per scan")
     ap.add_argument("--event-every", type=int, default=8,
                     help="bracket the fused kernel with HIP events on every k-th timed step")
     return ap
+
+
+def scans_per_launch(per_block, shards_max, max_hops, asked=0):
+    """C5: how many CONSECUTIVE scans share one persistent launch.  The largest divisor of `per_block` (the scans that
+    share a reduce block) whose accumulators -- `shards_max` per scan for the rank with the most shards -- fit the
+    kernel's hop table (`max_hops` = rpf_max_hops_per_launch()); `asked` > 0 caps it (1 = a launch per scan)."""
+    fit = [d for d in range(1, per_block + 1) if per_block % d == 0 and d * shards_max <= max_hops]
+    if asked > 0:
+        fit = [d for d in fit if d <= asked]
+    return max(fit or [1])
+
+
+def block_row(hop, sub, hops, k_scan):
+    """Row of (hop, scan `sub`) in a reduce block of per_block scans x `hops` spectra: launch batch b = sub // k_scan
+    first, then hop, then scan of the batch -- the spectra one launch writes (a rank's consecutive hops x the batch's
+    scans, or one hop x fewer scans) are then CONSECUTIVE rows, which is what rpf_device_reduce writes."""
+    return (sub // k_scan) * hops * k_scan + hop * k_scan + sub % k_scan
 
 
 class LaunchError(Exception):
@@ -460,6 +480,7 @@ def main():
     window = rpf.synth.hann_window(N) if wl["window"] else None
     ds = rpf.Datastore(rpf.Params(N=N, window=window is not None, repeats=R), window, device=dev.index or 0,
                        flags=args.engine_flags)
+    ds_max_hops = ds.max_hops_per_launch()
     # Exchange: one block = the `hops` spectra of a scan (C5) or of `hops`=8 consecutive
     # acquisitions (C2-C4), reduced onto rank 0 with ONE async RCCL reduce -- fewer, larger collectives --
     # on a ring of blocks so that it overlaps the following steps' kernels.
@@ -467,38 +488,65 @@ def main():
     # per scan at one per scan against a 33 us per-rank step at 8 ranks).
     per_block = max(1, args.scans_per_reduce) if strong else 8       # steps whose spectra share a block
     rows = hops * per_block if strong else per_block
-    nring = 4
-    # (strong scaling: rank 0 owns only some rows of a block and must clear the others before reuse;
-    # weak scaling: every rank rewrites every row, nothing to clear)
-    ring = rpf.sharding.ScanRing(rows, N, dev, nring=nring, dst=0, enabled=use_dist, clear_on_reuse=strong,
-                                 host_staged=gloo)
-    d_pwr = ring.blocks
-    s = torch.cuda.current_stream().cuda_stream
+    # C5: a rank's hops of k_scan CONSECUTIVE scans share one persistent launch (round 6; each (scan, hop) keeps its own
+    # accumulator -- to the kernel they are m x k_scan hops, rpf_device_fused_hops): the ~10 us of per-launch fixed cost
+    # are paid once per k_scan scans instead of once per scan, which is what an 8-rank job's 23 us of streaming per scan
+    # needs.  k_scan is the same on every rank (the block layout below depends on it): the largest divisor of
+    # per_block that fits the kernel's hop table for the rank with the most shards.
+    k_scan = 1
+    if strong:
+        ranks_of_job = args.shard_as or world
+        m_max = max(len(rpf.sharding.shard_hops(hops, R, ranks_of_job, r)) for r in range(ranks_of_job))
+        k_scan = scans_per_launch(per_block, m_max, ds_max_hops, args.scans_per_launch)
 
-    def step(i, ev=None):
+    def row_of(hop, sub):
+        return block_row(hop, sub, hops, k_scan)
+
+    def launch_scans(i, n, hop_ids, blk, ev=None):
+        """Scans i .. i+n-1 of this rank's shards `hop_ids` (indices into `mine`) in ONE persistent launch + ONE reduce
+        (rpf_accumulate_device_hops' two halves, so that the events bracket the fused kernel alone)."""
+        ptrs, nbytes, counts = [], [], []
+        for h in hop_ids:
+            for j in range(n):
+                ptrs.append(bufs[(i + j) % nb][h].data_ptr())
+                nbytes.append(2 * N * mine[h][2])
+                counts.append(mine[h][2])
+        if ev is not None:
+            ev[0].record()
+        ds.device_fused_hops(ptrs, nbytes, counts, s)
+        if ev is not None:
+            ev[1].record()
+        ds.device_reduce(d_pwr[blk][row_of(mine[hop_ids[0]][0], i % per_block)].data_ptr(), s)
+
+    def step(i, ev=None, limit=None):
+        """Step i of a region of `limit` steps (None: open-ended).  C5: the launches cover k_scan steps at a time, so the
+        steps in between have nothing left to do."""
         blk, sub = (i // per_block) % nring, i % per_block
+        if strong:
+            if sub % k_scan:
+                return blk
+            n = k_scan if limit is None else min(k_scan, limit - i)
+            if sub == 0:
+                ring.begin(blk)
+            if n == k_scan or len(mine) == 1:
+                launch_scans(i, n, list(range(len(mine))), blk, ev)
+            else:                       # a region's ragged tail: hop by hop, so that each launch's rows are consecutive
+                for h in range(len(mine)):
+                    launch_scans(i, n, [h], blk, ev if h == 0 else None)
+            if sub + n == per_block:
+                ring.submit(blk)
+            return blk
         if sub == 0:
             ring.begin(blk)
         streams = bufs[i % nb]
-        if strong:
-            # the rank's hops of the scan in ONE persistent launch + ONE reduce (rpf_accumulate_device_hops'
-            # two halves, so that the events bracket the fused kernel alone)
-            if ev is not None:
+        for k, (hop, first, count) in enumerate(mine):
+            out_row = d_pwr[blk][sub]
+            if ev is not None and k == 0:
                 ev[0].record()
-            ds.device_fused_hops([b.data_ptr() for b in streams], [2 * N * c for _, _, c in mine],
-                                 [c for _, _, c in mine], s)
-            if ev is not None:
+            ds.device_fused(streams[k].data_ptr(), 2 * N * count, count, s)
+            if ev is not None and k == 0:
                 ev[1].record()
-            ds.device_reduce(d_pwr[blk][sub * hops + mine[0][0]].data_ptr(), s)
-        else:
-            for k, (hop, first, count) in enumerate(mine):
-                out_row = d_pwr[blk][sub]
-                if ev is not None and k == 0:
-                    ev[0].record()
-                ds.device_fused(streams[k].data_ptr(), 2 * N * count, count, s)
-                if ev is not None and k == 0:
-                    ev[1].record()
-                ds.device_reduce(out_row.data_ptr(), s)
+            ds.device_reduce(out_row.data_ptr(), s)
         if sub == per_block - 1:
             ring.submit(blk)
         return blk
@@ -535,21 +583,25 @@ def main():
     prewarm_steps = i
     fence(i - 1)
     for i in range(args.warmup):
-        step(i)
+        step(i, limit=args.warmup)
     fence(args.warmup - 1 if args.warmup else None)
 
     events = []
     regions = []
     my_regions = []
     last_blk = 0
+    fused_before = ds.fused_status()
     while True:
         t0 = time.perf_counter()
         for i in range(args.steps):
             ev = None
-            if args.event_every > 0 and i % args.event_every == 0 and len(events) < 4096:
+            # (C5: only the steps that launch -- every k_scan-th -- and only whole batches, so that the brackets are
+            #  all launches of the same size)
+            if args.event_every > 0 and i % args.event_every == 0 and len(events) < 4096 and (
+                    not strong or (i % k_scan == 0 and i + k_scan <= args.steps)):
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 events.append(ev)
-            last_blk = step(i, ev)
+            last_blk = step(i, ev, limit=args.steps)
         fence(args.steps - 1)
         elapsed = time.perf_counter() - t0
         my_regions.append(elapsed)
@@ -563,12 +615,19 @@ def main():
         if len(regions) >= target:
             break
     elapsed = float(np.median(regions))
+    # A fused four-step launch that gives up returns RPF_OK and a NaN spectrum (include/rpf_engine.h): a timed region that
+    # contains one has timed work that produced nothing, and its line would be invalid.
+    fused_after = ds.fused_status()
+    if fused_after["gave_up"] > fused_before["gave_up"]:
+        print("bench.py: rank %d: %d fused four-step launch(es) gave up inside the timed regions (NaN spectra): no line"
+              % (rank, fused_after["gave_up"] - fused_before["gave_up"]), file=sys.stderr)
+        sys.exit(3)
 
     # ---- C5: the reduced spectra of the last scan against the committed fixtures -----------------
     check = None
     if strong and rank == 0 and not args.shard_as:
         last_sub = (args.steps - 1) % per_block
-        got = d_pwr[last_blk][last_sub * hops:(last_sub + 1) * hops].cpu().numpy()
+        got = d_pwr[last_blk][[row_of(hop, last_sub) for hop in range(hops)]].cpu().numpy()
         worst = 0.0
         for hop in range(hops):
             g = np.load(os.path.join(ROOT, "tests", "golden", "c5_hop%d_n4096_r5000.npz" % hop))
@@ -578,32 +637,41 @@ def main():
                  "fixtures": "tests/golden/c5_hop*_n4096_r5000.npz"}
         assert worst < 1e-6, "reduced C5 spectra differ from the fixtures: %g" % worst
 
-    # the same scan on ONE GPU (rank 0 alone, after the measurement): the strong-scaling comparator
-    one_gpu = None
-    if strong and world > 1:
-        if rank == 0:
-            all_hops = [rpf.synth.noise_tones_iq_torch(wl["seed"] + h, N * R, dev) for h in range(hops)]
-            d_one = torch.zeros(hops, N, dtype=torch.float64, device=dev)
+    # the C5 scan on ONE GPU (rank 0 alone, after the measurement, same launch form: as many consecutive scans per launch
+    # as the hop table takes): the strong-scaling comparator.  In EVERY C5 line, N = 1 included, and -- as
+    # `multi_gpu_reference` -- in the C2 line a `--gpus 1` run prints, so that a 1 / 2 / 4 / 8 sweep of `value` (C2 at
+    # one rank, C5 at several) carries its own same-workload denominator.
+    def one_gpu_scan_rate():
+        c5 = WORKLOADS["C5"]
+        n5, r5, h5 = c5["N"], c5["R"], c5["hops"]
+        all_hops = [rpf.synth.noise_tones_iq_torch(c5["seed"] + h, n5 * r5, dev) for h in range(h5)]
+        per = max(1, ds_max_hops // h5)
+        d_one = torch.zeros(per * h5, n5, dtype=torch.float64, device=dev)
+        ptrs = [a.data_ptr() for a in all_hops] * per
 
-            def scan():
-                ds.accumulate_device_hops([a.data_ptr() for a in all_hops], [2 * N * R] * hops, [R] * hops,
-                                          d_one.data_ptr(), s)
-            for _ in range(20):
-                scan()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            nscan = 100
-            for _ in range(nscan):
-                scan()
-            torch.cuda.synchronize()
-            one_gpu = hops * R * N * nscan / (time.perf_counter() - t0)
-            del all_hops
-        dist.barrier()
+        def scans():
+            ds.accumulate_device_hops(ptrs, [2 * n5 * r5] * (per * h5), [r5] * (per * h5), d_one.data_ptr(), s)
+        for _ in range(10):
+            scans()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nlaunch = 50
+        for _ in range(nlaunch):
+            scans()
+        torch.cuda.synchronize()
+        return h5 * r5 * n5 * per * nlaunch / (time.perf_counter() - t0), per
+
+    one_gpu = None
+    if (strong and not args.shard_as) or (name == "C2" and world == 1 and selected.startswith("auto")):
+        if rank == 0:
+            one_gpu = one_gpu_scan_rate()
+        if use_dist:
+            dist.barrier()
 
     # every rank's own view of the timed region (so that a multi-GPU run explains itself): its wall time
     # for the K steps, its fused-kernel bracket, what it processed
     k1_all = [a.elapsed_time(b) for a, b in events]
-    mine_report = {"rank": rank, "device": torch.cuda.get_device_name(dev), "region_s_median": float(np.median(my_regions)),
+    mine_report = {"rank": rank, "device": torch.cuda.get_device_name(dev), "device_index": dev.index or 0, "region_s_median": float(np.median(my_regions)),
                    "kernel_ms_median": float(np.median(k1_all)) if k1_all else None,
                    "frames_per_step": sum(m[2] for m in mine) if strong else mine[0][2],
                    "hops_per_step": len(mine) if strong else 1,
@@ -622,8 +690,8 @@ def main():
         k1_ms = float(np.median(k1_all)) if events else None
         k1_mean_ms = float(np.mean(k1_all)) if events else None
         # one launch of the dominant kernel: one acquisition (C2-C4), the rank's hops of the scan (C5)
-        frames_per_launch = sum(m[2] for m in mine) if strong else mine[0][2]
-        hops_per_launch = len(mine) if strong else 1
+        frames_per_launch = k_scan * sum(m[2] for m in mine) if strong else mine[0][2]
+        hops_per_launch = k_scan * len(mine) if strong else 1
         alg_bytes = 2 * N * frames_per_launch + hops_per_launch * 8 * N + (4 * N if window is not None else 0)
         info = ds.launch_info()
         roof = None
@@ -636,6 +704,8 @@ def main():
                     tj = json.load(open(tpath))
                     key = {"C2": "fft_accum_c2", "C3": "fft_accum_c3", "C4": "fourstep_c4", "C5": "fft_accum_c5"}[name]
                     traffic = tj.get(key + "_hbm_bytes_per_launch")
+                    if traffic and strong:      # captured per ONE-scan launch of all 8 hops: scaled to this launch's share
+                        traffic = traffic * frames_per_launch / float(hops * R)
                     traffic_note = "%s; captured %s" % (tj.get("source"), tj.get("captured", "round 1 (date not recorded)"))
                     measured_peak = tj.get("measured_read_only_GBps")   # tools/hbm_read_bench.hip, same box type
                 except Exception:
@@ -643,7 +713,9 @@ def main():
             # (which four-step kernel ran is what the ENGINE says -- rpf_fused_status --, not what the flags asked for:
             #  an engine whose teams did not assemble at creation is on the two-kernel path)
             fused = ds.fused_status()
-            kernel = ("fft_accum_kernel<N=4096,P=16> (K1)" if N == 4096 else
+            kernel = ("fft_accum_scan_kernel<N=4096,P=16> (K1: %d shard(s) x %d consecutive scan(s) = %d accumulators in one "
+                      "persistent launch)" % (len(mine), k_scan, hops_per_launch) if strong else
+                      "fft_accum_kernel<N=4096,P=16> (K1)" if N == 4096 else
                       "fourstep_fused_kernel<Split<512,512>> (one persistent launch per acquisition, Y handed over in the XCDs' L2)"
                       if fused["active"] else
                       "fourstep transform of one acquisition (two-kernel path: all batches of the column/row kernels)")
@@ -678,6 +750,7 @@ def main():
                        "workload_name": name, "workload_selected": selected,
                        "launch": info,
                        "shards_of_rank0": [list(m) for m in mine] if strong else None,
+                       "scans_per_launch": k_scan if strong else None,
                        "reduce": ("one async %s reduce of %d x %d f64 bins per %s" % (
                            "gloo (staged through pinned host memory)" if gloo else "RCCL",
                            rows, N, ("%d scans" % per_block if per_block > 1 else "scan") if strong else "8 steps"))
@@ -688,6 +761,16 @@ def main():
         }
         if use_dist:
             out["per_rank"] = per_rank
+            # what the collective library saw (so that a reader of the line can tell an N-rank RCCL run from a rehearsal)
+            if gloo:
+                out["rccl"] = {"world_size": 0, "version": None, "backend": "gloo (host-staged rehearsal): RCCL not used"}
+            else:
+                try:
+                    ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+                except Exception:
+                    ver = None
+                out["rccl"] = {"world_size": dist.get_world_size(), "version": ver, "backend": dist.get_backend(),
+                               "devices": sorted(set(p["device_index"] for p in per_rank))}
         if args.share_device:
             out["rehearsal"] = ("%d ranks share device 0 and time-slice it; the exchange is a gloo reduce staged through "
                                 "the host: launcher, shards, ring reuse, per-rank reports and the fixture check are what "
@@ -698,8 +781,12 @@ def main():
         if check:
             out["check"] = check
         if one_gpu:
-            out["one_gpu_same_workload"] = {"value": one_gpu, "unit": "samples/s",
-                                            "what": "the same 8-hop scan on rank 0's GPU alone, no reduce"}
+            ref = {"value": one_gpu[0], "unit": "samples/s", "scans_per_launch": one_gpu[1],
+                   "what": "config C5's 8-hop scan on rank 0's GPU alone, no reduce"}
+            if strong:
+                out["one_gpu_same_workload"] = ref
+            else:       # the C2 line of a one-rank run: what a --gpus N > 1 run of this script (C5) is to be divided by
+                out["multi_gpu_reference"] = dict(ref, workload_name="C5")
         if world == 1 and not args.force_dist:
             # rank 0's first shard on the host for the CPU legs
             host = base[0].cpu().numpy()

@@ -220,13 +220,9 @@ int rpf_scan_reducer_reduce(rpf_scan_reducer* r, int hops, double* host_out /* h
  *                      read it after synchronising the stream; a count that has grown means the spectrum of that
  *                      launch is NaN and must be asked for again (the engine is on the two-kernel path by then).
  *   *launches_recovered  of those, the ones the buffer-queue worker ran again on the two-kernel path
- * Any pointer may be NULL.  Not to be called while an acquisition is running. */
-int rpf_fused_status(const rpf_engine* e, int* active, int64_t* launches_gave_up, int64_t* launches_recovered);
-/* Test hook (tests/test_gpu_fused_abort.py): sabotage fused launches -- after `skip` untouched ones the next
- * `count` (< 0: all) launches fail to assemble.  mode 1: the launch finds a 33rd workgroup on XCD 0 and gives up at
- * once; mode 2: one CU is held by a squatter kernel until the launch has given up (the real failure, seconds);
- * mode 0: disarm.  No effect on an engine that is not on the fused kernel. */
-int rpf_debug_fused_fault(rpf_engine* e, int mode, int skip, int count);
+ * Any pointer may be NULL.  Not to be called while an acquisition is running.  NOT a pure query (hence no const): a call
+ * that finds a device-resident launch to have given up retires the fused kernel for this engine then and there. */
+int rpf_fused_status(rpf_engine* e, int* active, int64_t* launches_gave_up, int64_t* launches_recovered);
 
 /* Launch geometry of the last fused-kernel launch (for DESIGN/bench reporting):
  * workgroups, threads per workgroup, frames per workgroup, LDS bytes. */

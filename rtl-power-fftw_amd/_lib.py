@@ -91,13 +91,22 @@ _SYMBOLS = [
     ("rpf_stream_unregister", ctypes.c_int, [_P, _P]),
     ("rpf_fused_status", ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64),
                                         ctypes.POINTER(ctypes.c_int64)]),
-    ("rpf_debug_fused_fault", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     ("rpf_last_launch_info", ctypes.c_int, [_P] + [ctypes.POINTER(ctypes.c_int)] * 4),
+]
+
+
+# test hooks (csrc/rpf_engine_testing.h): exported by the library, NOT part of include/rpf_engine.h
+_TEST_HOOKS = [
+    ("rpf_debug_fused_fault", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
 ]
 
 
 def symbol_names():
     return [s[0] for s in _SYMBOLS]
+
+
+def test_hook_names():
+    return [s[0] for s in _TEST_HOOKS]
 
 
 def lib_path():
@@ -134,7 +143,7 @@ def load():
         except ImportError:
             pass
     lib = ctypes.CDLL(path)
-    for name, restype, argtypes in _SYMBOLS:
+    for name, restype, argtypes in _SYMBOLS + _TEST_HOOKS:
         fn = getattr(lib, name)
         fn.restype = restype
         fn.argtypes = argtypes

@@ -133,7 +133,7 @@ using WidePlan2 = typename WidePlanOf<PL>::type2;
 // the parity bar against the CPU path on at least one of the recorded tone streams (profiles/r04_fullsize_errors.json:
 // 8.3e-7 ... 9.96e-7 from 42000 bins up), and so do four smaller sizes (8.0 ... 8.6e-7).  Below, the float pass keeps
 // >= 20 % and its speed (the wide pass costs 7 % in the median and up to 2 x where its 4 R_last registers spill).
-// DESIGN.md 6; RPF_SPLIT_WIDE=0 (make nowide): every form on the float pass, for A/B.
+// DESIGN.md 6; RPF_SPLIT_WIDE=0 (make f32pass): every form on the float pass, for A/B.
 #ifndef RPF_SPLIT_WIDE
 #define RPF_SPLIT_WIDE 1
 #endif

@@ -19,6 +19,7 @@
 // straddles two slots (datastore.cxx:52,68,81) is completed by copying the tail of the previous staging slot in front
 // of the new bytes, device to device.
 #include "../../include/rpf_engine.h"
+#include "rpf_engine_testing.h"
 
 #include <hip/hip_runtime_api.h>
 
@@ -1437,11 +1438,10 @@ int rpf_stream_unregister(rpf_engine* e, const void* stream)
     return fail(e, RPF_ERR_INVALID_ARGUMENT, "rpf_stream_unregister: not a registered stream");
 }
 
-int rpf_fused_status(const rpf_engine* e, int* active, int64_t* launches_gave_up, int64_t* launches_recovered)
+int rpf_fused_status(rpf_engine* e, int* active, int64_t* launches_gave_up, int64_t* launches_recovered)
 {
     if (!e) return RPF_ERR_INVALID_ARGUMENT;
-    rpf_engine* me = const_cast<rpf_engine*>(e);
-    if (me->fused && !me->worker_running) note_device_path_aborts(me);
+    if (e->fused && !e->worker_running) note_device_path_aborts(e);
     if (active) *active = (e->fourstep && e->fused) ? 1 : 0;
     if (launches_gave_up) *launches_gave_up = e->h_fused_words ? __atomic_load_n(&e->h_fused_words[4], __ATOMIC_ACQUIRE) : 0;
     if (launches_recovered) *launches_recovered = e->fused_recovered;

@@ -84,20 +84,25 @@ __device__ __forceinline__ void group_fft(int t, cf* x, const cf (&tw)[G::NPASS 
     phase_last<G>(x);
 }
 // The row transform's LAST pass, and pwr += |X|^2 from it.  x: the values as fetched for the last pass; acc[a] is register
-// a's bin as after phase_last.  -DRPF_FOURSTEP_WIDE=1 (`make fswide`, NOT shipped): that pass in double, like the split
-// forms' (dft_small_wide.h).  Measured (profiles/r05_fourstep_wide.txt): at 131072 / 262144 bins the GPU then sits
-// 0.58 - 0.84e-6 from float64 truth instead of 1.3 - 2.5e-6, for 2 % of C4's rate -- and 1.5 - 2.3e-6 from the CPU PATH
-// instead of 0.5 - 1.3e-6 (C4's own line bins: 1.59e-6 instead of 4.8e-7): at these power-of-two lengths the CPU path's
-// last passes are the same float32 butterflies as the kernel's and make the same roundings beside a line, so the two
-// agree with each other far better than either agrees with the truth.  north_star's bar is against the CPU path: the
-// shipped kernels keep the float32 pass.
+// a's bin as after phase_last.  WIDE: that pass in double, like the split forms' (dft_small_wide.h) -- the pass in which a
+// line's energy has collected in one butterfly, so that every float32 rounding inside it lands on the weak bins beside
+// the line.  Shipped from kFourstepWideFrom bins up (round 6): measured (profiles/r05_fourstep_wide.txt,
+// r06_fourstep_wide.txt) the GPU then sits 0.6 - 0.8e-6 from float64 truth at 131072 / 262144 bins instead of 1.3 - 2.5e-6,
+// for 2 % of C4's rate.  It also moves the GPU AWAY from oracle/rpf_oracle.c on the line bins (C4: 4.8e-7 -> 1.6e-6): at these
+// power-of-two lengths the oracle's radix-4 / 2 float32 butterflies and the float32 pass make the same roundings beside a line
+// and agree with each other far better than either agrees with the truth.  The reference's arithmetic is FFTW's
+// (/root/reference/src/datastore.cxx:82), whose codelets share neither's roundings, and |gpu - FFTW| <= |gpu - truth| +
+// |FFTW - truth|: the distance from the truth is the objective, the agreement with the (unpinned) oracle was an artefact.
+// -DRPF_FOURSTEP_WIDE=0 (`make fsfloat`, A/B only) builds every size on the float32 pass, =1 every size on the wide one.
 #ifndef RPF_FOURSTEP_WIDE
-#define RPF_FOURSTEP_WIDE 0
+#define RPF_FOURSTEP_WIDE -1
 #endif
-template <class G>
+constexpr int kFourstepWideFrom = 131072;
+constexpr bool fourstep_is_wide(int n) { return RPF_FOURSTEP_WIDE < 0 ? n >= kFourstepWideFrom : RPF_FOURSTEP_WIDE != 0; }
+template <class G, bool WIDE>
 __device__ __forceinline__ void last_pass_accumulate(cf* x, double* acc)
 {
-    if constexpr (RPF_FOURSTEP_WIDE) {
+    if constexpr (WIDE) {
         constexpr int R = G::RLAST;
 #pragma unroll
         for (int g = 0; g < G::P / R; ++g) {
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_rows_kernel(const cf* __restr
 #pragma unroll
         for (int a = 0; a < G::P; ++a) x[a] = tile[(t + T * a) * S::ROW_PITCH + jrow];
         group_fft_but_last<G, false>(t, x, tw, slab, nullptr);
-        last_pass_accumulate<G>(x, acc);
+        last_pass_accumulate<G, fourstep_is_wide(S::N)>(x, acc);
         exchange_sync<false>();
     }
 
@@ -374,7 +379,7 @@ __device__ int g_fused_knob[4];
 #ifndef RPF_FUSED_KNOB1
 #define RPF_FUSED_KNOB1 0
 #endif
-#define FKNOB(i) ((i) == 1 ? RPF_FUSED_KNOB1 : 0)      // (make fexp: knob 1 at compile time, everything else as shipped)
+#define FKNOB(i) ((i) == 1 ? RPF_FUSED_KNOB1 : 0)      // (-DRPF_FUSED_KNOB1=n: knob 1 at compile time; round 4's A/B, profiles/r04_c4_fused.txt)
 #endif
 constexpr unsigned kSpinLimit = 4u << 20;      // global polls of ~0.1-3 us: >= 0.5 s
 constexpr unsigned kLdsSpinLimit = 1u << 26;   // LDS polls of ~50 ns
@@ -579,7 +584,7 @@ constexpr int fused_lds_bytes()
 // CU: 0.22 Tsample/s; 2 (shipped): a round's hand-offs hide behind the other buffer's work, 4 MB of Y cycle through a
 // 4 MB L2, all of it is written back once and about two thirds of the reads miss: 0.245.  NT (measurement only): the
 // consumers' tile loads and the raw rows carry the non-temporal hint -- no effect either way (profiles/r04_c4_fused.txt).
-// 3 (round 5's experiment, `make nbuf3`): the HALF-FRAME form -- Y in three buffers of HALF a round (the k1 tiles
+// 3 (round 5's experiment, -DRPF_FUSED_NBUF=3; profiles/r05_c4_halfframe.txt): the HALF-FRAME form -- Y in three buffers of HALF a round (the k1 tiles
 // [0, TPF/2) and [TPF/2, TPF) of every frame slot: 1 MB each), half round q = 2 j + h in buffer q mod 3; the producers
 // signal each half as its stores have drained, the sixteen consumer workgroups of a half start while the other half is
 // being stored; 3 MB of Y per 4 MB L2 (profiles/r04_l2_residency.txt: at that footprint the reads still hit).
@@ -988,7 +993,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                     // transforms, where the waves are skewed, cost 1.5 us per round
                     if (g == GROUPS - 1) role_arrive(sy, 2, lane);
                     if (!FKNOB(2)) group_fft_but_last<GB, true>(t, x, tw, slab, twtabB);
-                    last_pass_accumulate<GB>(x, acc[g]);
+                    last_pass_accumulate<GB, fourstep_is_wide(S::N)>(x, acc[g]);
                     exchange_sync<false>();
                 }
             } else {
@@ -1434,8 +1439,15 @@ hipError_t launch_fourstep_fused(int N, bool window, bool use_dma, const uint8_t
     } else if (fault == 2) {
         // (tests) one CU is taken before the launch: 255 workgroups register, the 256th cannot start, the spins run out.
         // The squatter leaves when it sees this launch's abort flag, so the flag must be clear before it starts.
-        static hipStream_t squat_stream = nullptr;
-        static unsigned* running = nullptr;
+        // Squatter state per DEVICE, under a lock (two engines on two devices, or two threads, may arm the hook)
+        struct Squat { hipStream_t stream = nullptr; unsigned* running = nullptr; };
+        static std::mutex squat_mutex;
+        static Squat squats[64];
+        int squat_device = 0;
+        if ((err = hipGetDevice(&squat_device)) != hipSuccess) return err;
+        std::lock_guard<std::mutex> squat_lock(squat_mutex);
+        hipStream_t& squat_stream = squats[squat_device & 63].stream;
+        unsigned*& running = squats[squat_device & 63].running;
         // (the whole device idle: a kernel still running elsewhere would let this launch's workgroups in first)
         if ((err = hipDeviceSynchronize()) != hipSuccess) return err;
         if (!squat_stream && (err = hipStreamCreateWithFlags(&squat_stream, hipStreamNonBlocking)) != hipSuccess) return err;

@@ -47,9 +47,11 @@ namespace {
 // Frames past the end are clamped to the last frame (never accumulated) so that
 // every iteration issues the same number of DMA instructions and the counted
 // s_waitcnt vmcnt(N) at the top of the frame loop stays exact.
-template <class G, bool DMA>
-__device__ __forceinline__ void stage_raw(const uint8_t* __restrict__ stream, int fb,
-                                          int nframes, uint8_t* wave_raw, int wave, int lane)
+// IDX: the frame index type -- long in the single-acquisition kernel, int in the
+// scan kernel (a hop's frames; one 64-bit multiply less per DMA instruction).
+template <class G, bool DMA, typename IDX>
+__device__ __forceinline__ void stage_raw(const uint8_t* __restrict__ stream, IDX fb, IDX nframes,
+                                          uint8_t* wave_raw, int wave, int lane)
 {
     constexpr int PIECES = G::P / 8;
     constexpr int FRAME_BYTES = 2 * G::N;
@@ -58,7 +60,7 @@ __device__ __forceinline__ void stage_raw(const uint8_t* __restrict__ stream, in
         const int j = i * 1024 + lane * 16;
         int slot, off;
         raw_source<G>(wave, j, &slot, &off);
-        int f = fb + slot;
+        IDX f = fb + slot;
         f = f < nframes ? f : nframes - 1;
         const uint8_t* src = stream + static_cast<long>(f) * FRAME_BYTES + off;
         if constexpr (DMA) {
@@ -75,37 +77,6 @@ __device__ __forceinline__ void stage_raw(const uint8_t* __restrict__ stream, in
 // the stream.  (The scan kernel below walks several acquisitions per launch; for a single one
 // this plain form measured 1.2 us per launch faster on the same box -- A/B in
 // profiles/r03_k1_fixed_cost.txt -- so rpf_accumulate / rpf_accumulate_device keep it.)
-// (64-bit frame indices: the single-acquisition kernel)
-// Stage the raw bytes this wavefront will unpack in the iteration whose slot-0
-// frame is `fb` (wave-local, a-major layout: fft_core.h raw_source).  P/8
-// instructions per wave, each moving 64 lanes x 16 B = eight 128-byte rows.
-// Frames past the end are clamped to the last frame (never accumulated) so that
-// every iteration issues the same number of DMA instructions and the counted
-// s_waitcnt vmcnt(N) at the top of the frame loop stays exact.
-template <class G, bool DMA>
-__device__ __forceinline__ void stage_raw64(const uint8_t* __restrict__ stream, long fb,
-                                          long nframes, uint8_t* wave_raw, int wave, int lane)
-{
-    constexpr int PIECES = G::P / 8;
-    constexpr int FRAME_BYTES = 2 * G::N;
-#pragma unroll
-    for (int i = 0; i < PIECES; ++i) {
-        const int j = i * 1024 + lane * 16;
-        int slot, off;
-        raw_source<G>(wave, j, &slot, &off);
-        long f = fb + slot;
-        f = f < nframes ? f : nframes - 1;
-        const uint8_t* src = stream + f * FRAME_BYTES + off;
-        if constexpr (DMA) {
-            // LDS address = wave-uniform base + 16 * lane (added by the hardware)
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wave_raw + i * 1024), 16, 0, 0);
-        } else {
-            *reinterpret_cast<uint4*>(wave_raw + j) = *reinterpret_cast<const uint4*>(src);
-        }
-    }
-}
-
-
 template <class G, int WG, int OCC, bool WINDOW, bool DMA, bool DBUF, int ACCB = 0, bool PF32 = false,
           int RAWD = 2, int ABL = 0, bool TWLDS = false>
 __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __restrict__ stream,
@@ -140,7 +111,7 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
     if (fb < nframes) {
 #pragma unroll
         for (int d = 0; d < RAWD; ++d)
-            stage_raw64<G, DMA>(stream, fb + d * stride, nframes, wave_raw + d * RAW_SLOT, wave, lane);
+            stage_raw<G, DMA, long>(stream, fb + d * stride, nframes, wave_raw + d * RAW_SLOT, wave, lane);
     }
 
     // Loop-invariant per-thread constants: twiddles, sign, window.
@@ -190,7 +161,7 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
             RPF_STAMP(clk, 1);                   // unpack
             // the slot has been consumed: refill it with the frame RAWD iterations ahead
             if constexpr (!(ABL & 8))
-                stage_raw64<G, DMA>(stream, fb + RAWD * stride, nframes, ring_slot, wave, lane);
+                stage_raw<G, DMA, long>(stream, fb + RAWD * stride, nframes, ring_slot, wave, lane);
             RPF_STAMP(clk, 3);                   // DMA issue
         }
 
@@ -353,7 +324,7 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_mfma_kernel(const uint8_t* 
     if (fb < nframes) {
 #pragma unroll
         for (int d = 0; d < RAWD; ++d)
-            stage_raw64<G, DMA>(stream, fb + d * stride, nframes, wave_raw + d * RAW_SLOT, wave, lane);
+            stage_raw<G, DMA, long>(stream, fb + d * stride, nframes, wave_raw + d * RAW_SLOT, wave, lane);
     }
 
     // loop-invariant: the matrix (A) fragments, the per-output constants, the later passes' twiddle table
@@ -408,7 +379,7 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_mfma_kernel(const uint8_t* 
                 }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot's reads have returned
         exchange_sync<false>();
-        stage_raw64<G, DMA>(stream, fb + RAWD * stride, nframes, ring_slot, wave, lane);
+        stage_raw<G, DMA, long>(stream, fb + RAWD * stride, nframes, ring_slot, wave, lane);
 
         f16x y[2];
 #pragma unroll
@@ -607,7 +578,7 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_scan_kernel(const cf* __res
         }
     };
     auto stage_next = [&](uint8_t* dst) {
-        stage_raw<G, DMA>(ahead.stream, ahead_fb, ahead.nframes, dst, wave, lane);
+        stage_raw<G, DMA, int>(ahead.stream, ahead_fb, ahead.nframes, dst, wave, lane);
         ahead_fb += ahead_fstep;
         if (--ahead_run == 0) ahead_turn();
     };
@@ -1188,20 +1159,8 @@ hipError_t launch_reduce_hops(const double* d_partial, const SlotRanges& slots, 
                                              stream, stride, d_skip);
         return hipGetLastError();
     }
-    int shape = 0;
-#ifdef RPF_TUNING
-    if (const char* sh = std::getenv("RPF_TUNE_K3")) shape = std::atoi(sh);     // A/B of the block shapes
-#endif
-    // (measured in situ behind K1, profiles/r03_k3_shapes.txt: all shapes within 0.3 us of each other)
-    switch (shape) {
-    case 1: launch_reduce_shape<double, 8, 32, 8>(d_partial, slots, H, N, d_out, accumulate, stream, stride); break;
-    case 2: launch_reduce_shape<double, 16, 16, 8>(d_partial, slots, H, N, d_out, accumulate, stream, stride); break;
-    case 3: launch_reduce_shape<double, 16, 16, 16>(d_partial, slots, H, N, d_out, accumulate, stream, stride); break;
-    case 4: launch_reduce_shape<double, 8, 16, 16>(d_partial, slots, H, N, d_out, accumulate, stream, stride); break;
-    case 5: launch_reduce_shape<double, 32, 8, 8>(d_partial, slots, H, N, d_out, accumulate, stream, stride); break;
-    case 6: launch_reduce_shape<double, 16, 32, 8>(d_partial, slots, H, N, d_out, accumulate, stream, stride); break;
-    default: launch_reduce_shape<double, 8, 16, 8>(d_partial, slots, H, N, d_out, accumulate, stream, stride, d_skip); break;
-    }
+    // one block shape: seven were measured in situ behind K1 within 0.3 us of each other (profiles/r03_k3_shapes.txt)
+    launch_reduce_shape<double, 8, 16, 8>(d_partial, slots, H, N, d_out, accumulate, stream, stride, d_skip);
     return hipGetLastError();
 }
 

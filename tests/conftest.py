@@ -11,6 +11,21 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: the full sweep (further tone streams per size); deselected unless "
+                                       "RPF_RUN_SLOW=1 -- tools/gpu_r06.sh final runs it, the driver's -m gpu does not")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`pytest -m gpu` must stay well inside the driver's step limit: the tests marked `slow` --
+    always `gpu` tests too -- leave the run unless RPF_RUN_SLOW=1."""
+    if os.environ.get("RPF_RUN_SLOW") == "1":
+        return
+    keep, drop = [], []
+    for item in items:
+        (drop if item.get_closest_marker("slow") else keep).append(item)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 def _have_sources():

@@ -101,3 +101,34 @@ def test_self_launch_reports_failing_ranks(tmp_path):
     quiet.write_text("print('nothing useful')\n")
     cmd = bench.plan_launch(parse("--gpus", "2"), [], {}, 2, script=str(quiet))
     assert bench.self_launch(cmd, io.StringIO()) == 1
+
+
+def test_scans_per_launch_and_the_block_layout():
+    """Config C5 (round 6): a rank's hops of k consecutive scans share one persistent launch.  k divides the scans
+    of a reduce block and k x (the most shards any rank owns) fits the kernel's hop table (16); the block's rows are
+    ordered so that whatever ONE launch writes -- a rank's consecutive hops x the k scans of a batch, or one hop x the
+    scans of a region's ragged tail -- is a run of consecutive rows (rpf_device_reduce writes n_hops x N contiguously)."""
+    import rtl_power_fftw_amd as rpf
+    hops, frames, per_block, table = 8, 5000, 4, 16
+    for world, want in ((1, 2), (2, 4), (3, 4), (4, 4), (8, 4)):
+        shards = [rpf.sharding.shard_hops(hops, frames, world, r) for r in range(world)]
+        k = bench.scans_per_launch(per_block, max(len(m) for m in shards), table)
+        assert k == want, (world, k)
+        assert bench.scans_per_launch(per_block, max(len(m) for m in shards), table, asked=1) == 1
+        # every (hop, scan) has a row of its own
+        rows = sorted(bench.block_row(h, sub, hops, k) for h in range(hops) for sub in range(per_block))
+        assert rows == list(range(hops * per_block))
+        for mine in shards:
+            hop_ids = [m[0] for m in mine]
+            assert hop_ids == list(range(hop_ids[0], hop_ids[0] + len(mine)))      # hop-major: consecutive hops
+            for first in range(0, per_block, k):
+                # a whole batch: hops outer, scans inner -- the order bench.py lists them in
+                got = [bench.block_row(h, first + j, hops, k) for h in hop_ids for j in range(k)]
+                assert got == list(range(got[0], got[0] + len(got)))
+                # a ragged tail of n < k scans goes hop by hop
+                for n in range(1, k):
+                    for h in hop_ids:
+                        got = [bench.block_row(h, first + j, hops, k) for j in range(n)]
+                        assert got == list(range(got[0], got[0] + n))
+    assert bench.scans_per_launch(1, 1, 16) == 1 and bench.scans_per_launch(6, 2, 16) == 6
+    assert bench.scans_per_launch(4, 20, 16) == 1          # (never fits: a launch per scan, hop by hop in the engine)

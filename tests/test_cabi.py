@@ -14,14 +14,30 @@ from rtl_power_fftw_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "rpf_engine.h")).read()
+def _declared_symbols(path=os.path.join(ROOT, "include", "rpf_engine.h")):
+    text = open(path).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(rpf_[a-z_0-9]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():
     assert _declared_symbols() == sorted(_lib.symbol_names())
+
+
+def test_test_hooks_are_not_part_of_the_boundary():
+    """The fault-injection entry lives in csrc/rpf_engine_testing.h: exported for tests/, absent from the ABI header,
+    and no host code (the C++ mirror of the reference's classes, the CLI) includes that header or calls it."""
+    hooks = _declared_symbols(os.path.join(ROOT, "rtl-power-fftw_amd", "csrc", "rpf_engine_testing.h"))
+    assert hooks == sorted(_lib.test_hook_names()) == ["rpf_debug_fused_fault"]
+    assert not any("debug" in name for name in _declared_symbols())
+    lib = ctypes.CDLL(_lib.lib_path())
+    for name in hooks:
+        assert hasattr(lib, name), name
+    host = os.path.join(ROOT, "rtl-power-fftw_amd", "host")
+    for f in os.listdir(host):
+        if f.endswith((".cpp", ".h")):
+            body = open(os.path.join(host, f)).read()
+            assert "rpf_engine_testing" not in body and "rpf_debug_" not in body, f
 
 
 def test_library_exports_every_declared_symbol():

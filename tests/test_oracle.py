@@ -294,14 +294,44 @@ def test_fftw_probe_pins_the_oracle_when_the_real_library_exists():
     from oracle import fftw_probe
     c1 = rpf.synth.uniform_iq(1, 512 * 100)
     rep = fftw_probe.report(512, c1, 100, {"oracle": oracle_accumulate(512, c1, 100)[0]})
-    if fftw_probe.load() is None:
-        assert rep == {"fftw": "absent"}
+    if fftw_probe.provider() != "fftw3f":
+        assert rep["fftw"] == "absent"
         pytest.skip("libfftw3f is not installed here: parity stays unpinned on this box")
     c2 = rpf.synth.noise_tones_iq(2, 4096 * 400)
     rep2 = fftw_probe.report(4096, c2, 400, {"oracle": oracle_accumulate(4096, c2, 400)[0]})
     for r in (rep, rep2):
+        assert r["fftw"] == "present" and r["provider"] == "fftw3f"
         for flag in ("measure", "estimate"):
             assert r[flag]["max_rel_vs_oracle"] < 1e-6, r
+
+
+def test_oracle_against_mkl_through_the_references_own_fftw3_calls():
+    """A fifth comparator, through the reference's own call sites: Intel MKL implements the FFTW3
+    API (libmkl_rt exports fftwf_plan_dft_1d / fftwf_execute / fftwf_malloc ...), so the probe's restatement of
+    datastore.cxx:30-33,66-89 -- plan with FFTW_MEASURE, fill inbuf, fftwf_execute, square and sum in double -- runs around
+    it unchanged.  It is MKL's arithmetic, not FFTW's, and pins nothing ("fftw" stays "absent"); what it shows is the
+    oracle within the parity bar of a float32 FFT nobody here wrote, called exactly as the reference calls its own:
+    C1, the heads of C2 and C3, a non-power-of-two size (the man page's -b 500) and a four-step size."""
+    import sys
+    sys.path.insert(0, __import__("helpers").ROOT)
+    from oracle import fftw_probe
+    if fftw_probe.load() is None:
+        pytest.skip("neither libfftw3f nor libmkl_rt on this box")
+    if fftw_probe.provider() == "fftw3f":
+        pytest.skip("this box has the real FFTW: the test above is the one that counts")
+    cases = ((512, 100, rpf.synth.uniform_iq(1, 512 * 100), None),
+             (4096, 400, rpf.synth.noise_tones_iq(2, 4096 * 400), None),
+             (4096, 400, rpf.synth.noise_tones_iq(2, 4096 * 400), rpf.synth.hann_window(4096)),
+             (500, 64, rpf.synth.noise_tones_iq(61, 500 * 64), None),
+             (65536, 64, rpf.synth.noise_tones_iq(62, 65536 * 64), None))
+    for N, R, stream, w in cases:
+        orc = oracle_accumulate(N, stream, R, w)[0]
+        rep = fftw_probe.report(N, stream, R, {"oracle": orc, "truth": truth_f64(N, stream, R, w)}, w)
+        assert rep["fftw"] == "absent" and rep["fftw3_api"]["provider"] == "mkl_fftw3_interface"
+        for flag in ("measure", "estimate"):
+            fig = rep["fftw3_api"][flag]
+            assert fig["frames"] == R
+            assert fig["max_rel_vs_oracle"] < 1e-6 and fig["max_rel_vs_truth"] < 1e-6, (N, rep)
 
 
 def test_oracle_against_mkl_the_third_float32_fft():

@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import rtl_power_fftw_amd as rpf  # noqa: E402
 from helpers import max_rel, oracle_accumulate, truth_f64  # noqa: E402
-from test_gpu_heldout import held_out_seeds  # noqa: E402
+from test_gpu_heldout import tuning_stream_seeds  # noqa: E402
 
 
 def load():
@@ -74,7 +74,7 @@ def main():
         windowed = arg.endswith(":w")
         window = rpf.synth.hann_window(N) if windowed else None
         only_stream = os.environ.get("STREAM")        # a, b or c: that held-out stream only
-        seeds = [sd for sd in held_out_seeds(N) if not only_stream or sd[0].endswith("_" + only_stream)]
+        seeds = [sd for sd in tuning_stream_seeds(N) if not only_stream or sd[0].endswith("_" + only_stream)]
         for name, seed in seeds[: int(os.environ.get("STREAMS", "3"))]:
             stream = rpf.synth.noise_tones_iq(seed, N * R)
             truth = truth_f64(N, stream, R, window)

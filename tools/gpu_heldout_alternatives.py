@@ -8,13 +8,13 @@ import numpy as np
 import torch
 import rtl_power_fftw_amd as rpf
 from helpers import max_rel, oracle_accumulate, truth_f64
-from test_gpu_heldout import held_out_seeds
+from test_gpu_heldout import tuning_stream_seeds
 from test_gpu_parity import run_device
 
 dev = torch.device("cuda:0")
 F = rpf._lib
 for N in [int(v) for v in sys.argv[1:]]:
-    for name, seed in held_out_seeds(N):
+    for name, seed in tuning_stream_seeds(N):
         stream = rpf.synth.noise_tones_iq(seed, N * 64)
         for windowed in (False, True):
             w = rpf.synth.hann_window(N) if windowed else None
