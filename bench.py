@@ -502,6 +502,14 @@ def main():
     def row_of(hop, sub):
         return block_row(hop, sub, hops, k_scan)
 
+    nring = 4
+    # (strong scaling: rank 0 owns only some rows of a block and must clear the others before reuse;
+    # weak scaling: every rank rewrites every row, nothing to clear)
+    ring = rpf.sharding.ScanRing(rows, N, dev, nring=nring, dst=0, enabled=use_dist, clear_on_reuse=strong,
+                                 host_staged=gloo)
+    d_pwr = ring.blocks
+    s = torch.cuda.current_stream().cuda_stream
+
     def launch_scans(i, n, hop_ids, blk, ev=None):
         """Scans i .. i+n-1 of this rank's shards `hop_ids` (indices into `mine`) in ONE persistent launch + ONE reduce
         (rpf_accumulate_device_hops' two halves, so that the events bracket the fused kernel alone)."""
@@ -704,8 +712,8 @@ def main():
                     tj = json.load(open(tpath))
                     key = {"C2": "fft_accum_c2", "C3": "fft_accum_c3", "C4": "fourstep_c4", "C5": "fft_accum_c5"}[name]
                     traffic = tj.get(key + "_hbm_bytes_per_launch")
-                    if traffic and strong:      # captured per ONE-scan launch of all 8 hops: scaled to this launch's share
-                        traffic = traffic * frames_per_launch / float(hops * R)
+                    if traffic and strong:      # captured per launch of N frames (rounds <= 5: one 40000-frame scan): scaled
+                        traffic = traffic * frames_per_launch / float(tj.get("fft_accum_c5_frames_per_launch", hops * R))
                     traffic_note = "%s; captured %s" % (tj.get("source"), tj.get("captured", "round 1 (date not recorded)"))
                     measured_peak = tj.get("measured_read_only_GBps")   # tools/hbm_read_bench.hip, same box type
                 except Exception:

@@ -67,7 +67,7 @@ struct Split {
     static constexpr int SLAB_A = SUBA * GA::LDS_CPX;                   // complex per wave
     static constexpr int SLAB_B = SUBB * GB::LDS_CPX;
     static constexpr int COLS_LDS = N1 * kRowDwords * 4 + kWaves * SLAB_A * (int)sizeof(cf);
-    static constexpr int ROWS_LDS = N2 * ROW_PITCH * (int)sizeof(cf) + kWaves * SLAB_B * (int)sizeof(cf);
+    static constexpr int ROWS_LDS = N2 * ROW_PITCH * (int)sizeof(cf) + kWaves * SLAB_B * (int)sizeof(cf) + 1040;   // + kWideTabBytes
     static constexpr int BATCH = (int)(kScratchBytes / (sizeof(cf) * (size_t)N));   // frames per launch pair
     static constexpr int GROUPS = (256 / ROW_TILES) < BATCH ? (256 / ROW_TILES) : BATCH;   // frame groups
     static_assert(GA::T <= 64 && GB::T <= 64 && COLS_PER_WAVE % SUBA == 0, "");
@@ -97,7 +97,7 @@ __device__ __forceinline__ void group_fft(int t, cf* x, const cf (&tw)[G::NPASS 
 #ifndef RPF_FOURSTEP_WIDE
 #define RPF_FOURSTEP_WIDE -1
 #endif
-constexpr int kFourstepWideFrom = 131072;
+constexpr int kFourstepWideFrom = 65536;
 constexpr bool fourstep_is_wide(int n) { return RPF_FOURSTEP_WIDE < 0 ? n >= kFourstepWideFrom : RPF_FOURSTEP_WIDE != 0; }
 template <class G, bool WIDE>
 __device__ __forceinline__ void last_pass_accumulate(cf* x, double* acc)
@@ -118,12 +118,144 @@ __device__ __forceinline__ void last_pass_accumulate(cf* x, double* acc)
         phase_accumulate(x, acc, G::P);
     }
 }
-// group_fft without its last pass's butterflies: the values as phase_fetch leaves them
-template <class G, bool TWLDS>
-__device__ __forceinline__ void group_fft_but_last(int t, cf* x, const cf (&tw)[G::NPASS - 1][G::P - 1], cf* slab, const cf* twtable)
+// The pass BEFORE the last multiplies by twiddles that are EXACT to double precision, not the float32 table's values.
+// Measured (profiles/r06_fourstep_wide.txt): with only the last pass in double 131072 bins stayed 0.4 - 1.4e-6 from
+// float64 truth, its worst bin always a weak deterministic LINE (bin 2N/16) that shares its last two butterflies with a
+// strong one; a float32 emulation of the transform (tools/analysis/fourstep_passes.py) keeps 1.3e-6 there with EVERY pass
+// in double as long as the twiddle TABLE is float32: the table's representation error (1.7e-8 on 1/sqrt(2)) is a
+// deterministic leak from the strong line into the weak one, the same in every frame, so it never averages down.  The
+// lines' path through the earlier passes (and through the whole column transform: lines sit at k1 = 0) only meets the
+// twiddle 1.  Three forms, RPF_FOURSTEP_WIDE2 =
+//   1 (shipped)  the pass's butterflies stay float32; each product is x (hi + lo), hi the float32 table's value and
+//                lo = float(exact - hi), read as one 16-byte (hi, lo) pair from a 0.4 - 0.9 KB LDS table: two more packed
+//                instructions per product, 14 per thread and transform, no more LDS instructions than before.  Emulated 2.3 - 5.3e-7 from the truth at 65536 ... 262144 bins.
+//   2 (A/B)      the whole pass in double with double twiddles: emulated 2.0 - 3.0e-7, measured 35 % of C4's rate.
+//   0 (A/B)      the last pass alone in double.
+#ifndef RPF_FOURSTEP_WIDE2
+#define RPF_FOURSTEP_WIDE2 1
+#endif
+// From kFourstepExactFrom bins up: at 65536 the last pass in double alone holds 1e-6 against the CPU path AND the truth on
+// every recorded stream (<= 7.8e-7 / 7.6e-7), and form 1 missed the CPU path by a hair on one (1.004e-6, the CPU path
+// itself 7.2e-7 from the truth there) -- the contract's comparator decides where it can.
+constexpr int kFourstepExactFrom = 131072;
+template <class G>
+constexpr int fourstep_wide2(int n) { return fourstep_is_wide(n) && n >= kFourstepExactFrom && G::NPASS >= 3 ? RPF_FOURSTEP_WIDE2 : 0; }
+// W_L^k = (cos, -sin)(2 pi k / L), k < L, in double (constexpr Taylor series of dft_small.h, ~1e-16)
+template <int L>
+struct WideTwiddleTable {
+    double c[L], s[L];
+    constexpr WideTwiddleTable() : c(), s()
+    {
+        for (int k = 0; k < L; ++k) {
+            c[k] = cos_turn(k, L);
+            s[k] = -sin_turn(k, L);
+        }
+    }
+};
+template <int L>
+__device__ constexpr WideTwiddleTable<L> kWideTwiddles{};
+// The kernels read them from LDS (filled once per launch): form 2 as 16-byte doubles indexed by the exponent -- fetched
+// from global memory per transform they cost the fused kernel 28 % (14 scattered 8-byte loads per lane and transform in
+// a role whose memory queue is the tile loads'); form 1 as the float32 remainders, one row of P - 1 per m = t mod L_J,
+// laid out like fill_twlds lays out the table's own values.
+constexpr int kWideTabBytes = 64 * (int)sizeof(cd) + 16;      // L <= 64 entries + room to align to 16 bytes
+template <class G>
+constexpr bool fourstep_has_wide_table(int n) { return fourstep_wide2<G>(n) != 0; }
+// (the offset from the start of the LDS allocation is rounded up, not the pointer's integer value: a pointer that has been
+// through an integer loses its address space and every read of the table becomes a FLAT load on the vector memory path --
+// measured: that alone cost C4 16 %)
+template <class T>
+__device__ __forceinline__ cd* wide_table_at(unsigned char* smem, T* after)
 {
-    PhaseClock none;
-    middle_passes<G, 1, 0, TWLDS>(t, x, tw, slab, none, twtable);
+    const int off = static_cast<int>(reinterpret_cast<unsigned char*>(after) - smem);
+    return reinterpret_cast<cd*>(smem + ((off + 15) & ~15));
+}
+// twN: the master table W_N^k the pass's float32 twiddles come from (load_twiddles / fill_twlds read the same entries)
+template <class G, int MODE>
+__device__ __forceinline__ void fill_wide_table(cd* tab, int tid, int nthreads, const cf* __restrict__ twN)
+{
+    constexpr int J = G::NPASS - 1, L = G::Lprev(J);
+    static_assert(L <= 64 && G::Lcur(J) * (G::P - 1) * (int)sizeof(cf4) <= 64 * (int)sizeof(cd), "kWideTabBytes");
+    if constexpr (MODE == 2) {
+        for (int k = tid; k < L; k += nthreads) tab[k] = cd{kWideTwiddles<L>.c[k], kWideTwiddles<L>.s[k]};
+    } else {
+        cf4* const hl = reinterpret_cast<cf4*>(tab);             // {hi, lo} side by side: one 16-byte LDS read per product
+        for (int i = tid; i < G::Lcur(J) * (G::P - 1); i += nthreads) {
+            const int m = i / (G::P - 1), r = i % (G::P - 1) + 1;
+            const cf hi = twN[m * r * ipow(G::P, J - 1)];
+            cf4 e;
+            e.lo = hi;
+            e.hi = cf{static_cast<float>(kWideTwiddles<L>.c[m * r] - static_cast<double>(hi.x)),
+                      static_cast<float>(kWideTwiddles<L>.s[m * r] - static_cast<double>(hi.y))};
+            hl[i] = e;
+        }
+    }
+}
+// a (hi + lo): the small product first, the two large terms folded onto it -- four packed instructions
+__device__ __forceinline__ cf cmul_compensated(cf a, cf hi, cf lo)
+{
+    cf d;
+    asm("v_pk_mul_f32 %0, %1, %3 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %3, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+        : "=&v"(d)
+        : "v"(a), "v"(hi), "v"(lo));
+    return d;
+}
+// passes J ... NPASS-1 of a row transform (middle_passes of rpf_device_common.h), the pass before the last in form MODE
+template <class G, int J, bool TWLDS, int MODE>
+__device__ __forceinline__ void row_passes(int t, cf* x, const cf (&tw)[G::NPASS - 1][G::P - 1], cf* slab, const cf* twtable,
+                                           const cd* widetab)
+{
+    if constexpr (J < G::NPASS) {
+        if constexpr (J > 1) phase_fetch<G, J>(t, x, slab);
+        cf twj[G::P - 1];
+        if constexpr (MODE == 1 && J == G::NPASS - 1) {
+            // (hi, lo) pairs from the wide table below, not from the registers / the twiddle table
+        } else if constexpr (TWLDS && J >= 2) {
+            const cf* row = twtable + twlds_offset<G, J>() + (t % G::Lcur(J)) * (G::P - 1);
+#pragma unroll
+            for (int r = 0; r < G::P - 1; ++r) twj[r] = row[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < G::P - 1; ++r) twj[r] = tw[J - 1][r];
+        }
+        if constexpr (MODE == 2 && J == G::NPASS - 1) {
+            cd w[G::P];
+#pragma unroll
+            for (int a = 0; a < G::P; ++a) w[a] = cd{static_cast<double>(x[a].x), static_cast<double>(x[a].y)};
+            WideDft<G::P>::run(w);
+            x[0] = cf{static_cast<float>(w[0].x), static_cast<float>(w[0].y)};
+            const int m = t % G::Lcur(J);                // W_{L_{J-1}}^{m r}, m = t mod L_J (fft_core.h twiddle_index)
+#pragma unroll
+            for (int r = 1; r < G::P; ++r) {
+                const cd wr = widetab[m * r];
+                const cd v = wide_cmul(w[r], wr.x, wr.y);
+                x[r] = cf{static_cast<float>(v.x), static_cast<float>(v.y)};
+            }
+        } else if constexpr (MODE == 1 && J == G::NPASS - 1) {
+            const cf4* hl = reinterpret_cast<const cf4*>(widetab) + (t % G::Lcur(J)) * (G::P - 1);
+            Dft<G::P>::run(x);
+#pragma unroll
+            for (int r = 1; r < G::P; ++r) {
+                const cf4 e = hl[r - 1];
+                x[r] = cmul_compensated(x[r], e.lo, e.hi);
+            }
+        } else {
+            phase_butterfly_twiddle<G>(x, twj);
+        }
+        phase_store<G, J>(t, x, slab);
+        exchange_sync<(G::Lcur(J) > 64)>();
+        row_passes<G, J + 1, TWLDS, MODE>(t, x, tw, slab, twtable, widetab);
+    }
+}
+// group_fft without its last pass's butterflies: the values as phase_fetch leaves them
+template <class G, bool TWLDS, int MODE = 0>
+__device__ __forceinline__ void group_fft_but_last(int t, cf* x, const cf (&tw)[G::NPASS - 1][G::P - 1], cf* slab, const cf* twtable,
+                                                   const cd* widetab = nullptr)
+{
+    row_passes<G, 1, TWLDS, MODE>(t, x, tw, slab, twtable, widetab);
     phase_fetch<G, G::NPASS>(t, x, slab);
 }
 // The same with the twiddles of the passes >= 2 read from an LDS table (fill_twlds) instead of held in registers:
@@ -258,8 +390,11 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_rows_kernel(const cf* __restr
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* const tile = reinterpret_cast<cf*>(smem);                                   // [N2][ROW_PITCH]
     cf* const slabs = tile + N2 * S::ROW_PITCH;                                     // [16][SLAB_B]
+    cd* const widetab = wide_table_at(smem, slabs + kWaves * S::SLAB_B);                  // exact twiddles of the pass before the last
 
     const int tid = threadIdx.x;
+    if constexpr (fourstep_has_wide_table<G>(S::N))                                  // (the loop's first barrier covers it)
+        fill_wide_table<G, fourstep_wide2<G>(S::N)>(widetab, tid, kWG, tw_sub);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int sub = lane / T, t = lane % T;
     const int jrow = wave * S::SUBB + sub;                 // this lane group's row inside the tile
@@ -304,7 +439,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_rows_kernel(const cf* __restr
         cf x[G::P];
 #pragma unroll
         for (int a = 0; a < G::P; ++a) x[a] = tile[(t + T * a) * S::ROW_PITCH + jrow];
-        group_fft_but_last<G, false>(t, x, tw, slab, nullptr);
+        group_fft_but_last<G, false, fourstep_wide2<G>(S::N)>(t, x, tw, slab, nullptr, widetab);
         last_pass_accumulate<G, fourstep_is_wide(S::N)>(x, acc);
         exchange_sync<false>();
     }
@@ -533,12 +668,12 @@ __device__ __forceinline__ bool team_wait(FusedCtl* ctl, FusedSync* sy, const un
 }
 
 // -DRPF_FUSED_PROFILE: lane 0 of wave 0 of each role adds the wall-clock ticks (100 MHz) it spends in each segment
-// of a round to g_fused_prof (tools/gpu_fused_profile.py prints them); never in the shipped library.
+// of a round to g_fused_prof (printed by tools/gpu_fused_profile.py, which left the tree in round 6: `git show 71dca54:tools/gpu_fused_profile.py`); never in the shipped library.
 #ifdef RPF_FUSED_PROFILE
 __device__ unsigned long long g_fused_prof[16];
 __device__ unsigned long long g_fused_prof_wg[256][16];     // the same per workgroup (32 xcd + rank), last launch
 // absolute 100 MHz time stamps of the hand-offs, [workgroup = 32 xcd + rank][round < 64][event]: 0 producers arrived,
-// 1 consumers saw `produced`, 2 consumers arrived, 3 producers saw `consumed` (tools/gpu_fused_profile.py prints
+// 1 consumers saw `produced`, 2 consumers arrived, 3 producers saw `consumed` (that tool prints
 // where the signals spend their time)
 __device__ unsigned long long g_fused_trace[256][64][4];
 #define FTRACE(ev) do { if (rw == 0 && lane == 0 && j < 64) g_fused_trace[32 * xcd + rank][j][ev] = wall_clock64(); } while (0)
@@ -576,7 +711,7 @@ constexpr int fused_lds_bytes()
     constexpr int tile = S::N2 * S::ROW_PITCH * (int)sizeof(cf);
     constexpr int twtables = (twlds_entries<typename S::GA>() + twlds_entries<typename S::GB>()) * (int)sizeof(cf);
     constexpr int steptab = 16 * S::SUBA * 8 * (int)sizeof(cf);        // the register-index factor of W_N^{n2 k1}, per column
-    return slabs + tile + raw + twtables + steptab;
+    return slabs + tile + raw + twtables + steptab + kWideTabBytes;
 }
 
 // NBUF: buffers of Y per team.  1: the round's 2 MB stay in the L2 for good (every read hits, 39 % of the writes never
@@ -622,6 +757,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
     cf* const twtabA = reinterpret_cast<cf*>(raw + N1 * ROWB);                    // later passes' twiddles, columns
     cf* const twtabB = twtabA + twlds_entries<GA>();                                   // ... and rows
     cf* const steptab = twtabB + twlds_entries<GB>();                                  // [COLS][P]: W_N^{n2 (bin_of(0, a))}
+    cd* const widetab = wide_table_at(smem, steptab + COLS * P);                             // exact twiddles of the row transform's pass before the last
     __shared__ FusedSync sync_;
     FusedSync* const sy = &sync_;
 
@@ -630,6 +766,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
 
     fill_twlds<GA, 1>(tid, kWG, tw_n1, twtabA);
     fill_twlds<GB, 1>(tid, kWG, tw_n2, twtabB);
+    if constexpr (fourstep_has_wide_table<GB>(N)) fill_wide_table<GB, fourstep_wide2<GB>(N)>(widetab, tid, kWG, tw_n2);
     // ---- team assembly -------------------------------------------------------------------------
     if (tid == 0) {
         const int xcd = static_cast<int>(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20)) & 7;   // XCC_ID[3:0]
@@ -929,7 +1066,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                 // sc1 loads: served by the L2, never by this CU's L1 (other CUs wrote these lines); 16 bytes per lane,
                 // all eight of a thread's loads in flight -- and the wait for them in the SAME asm statement: the
                 // compiler does not know that an asm load's destination is written when the data returns, and is free
-                // to copy or reuse it before a separate s_waitcnt (tools/l2_residency_bench.hip met exactly that)
+                // to copy or reuse it before a separate s_waitcnt (round 4's L2 residency microbenchmark met exactly that: profiles/r04_l2_residency.txt)
                 f4 v[PERB];
                 static_assert(PERB == 8, "the tile is 8192 complex values");
                 const cf* src[PERB];
@@ -992,7 +1129,7 @@ __global__ __launch_bounds__(kWG, 4) void fourstep_fused_kernel(const uint8_t* _
                     // next round's tile write waits for all eight arrivals, by then long posted -- a barrier behind the
                     // transforms, where the waves are skewed, cost 1.5 us per round
                     if (g == GROUPS - 1) role_arrive(sy, 2, lane);
-                    if (!FKNOB(2)) group_fft_but_last<GB, true>(t, x, tw, slab, twtabB);
+                    if (!FKNOB(2)) group_fft_but_last<GB, true, fourstep_wide2<GB>(S::N)>(t, x, tw, slab, twtabB, widetab);
                     last_pass_accumulate<GB, fourstep_is_wide(S::N)>(x, acc[g]);
                     exchange_sync<false>();
                 }

@@ -128,11 +128,21 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
 #pragma unroll
         for (int a = 0; a < P; ++a) wsgn[a] = window[t + T * a] * sgn;
     }
+    // ACCB (tuning variants only): |X|^2 is first summed over ACCB frames in float32, then added to the double
+    // accumulators.  1 .. 99: one float per bin (two v_fma_f32; round 3's variant 22); 100 + n (round 6, VERDICT r05 item
+    // 4 i): PACKED, (re^2, im^2) kept apart in one register pair per bin -- ONE v_pk_fma_f32 per bin and frame -- over n
+    // frames.  Both depart from the reference's "square and sum in double" (datastore.cxx:83-85); neither is shipped.
+    constexpr bool ACCP = ACCB >= 100;
+    constexpr int ACCN = ACCP ? ACCB - 100 : ACCB;
     double acc[P];
-    float acc32[ACCB > 0 ? P : 1];
+    float acc32[ACCB > 0 && !ACCP ? P : 1];
+    cf acc32p[ACCP ? P : 1];
 #pragma unroll
     for (int a = 0; a < P; ++a) acc[a] = 0.0;
-    if constexpr (ACCB > 0) {
+    if constexpr (ACCP) {
+#pragma unroll
+        for (int a = 0; a < P; ++a) acc32p[a] = cf{0.0f, 0.0f};
+    } else if constexpr (ACCB > 0) {
 #pragma unroll
         for (int a = 0; a < P; ++a) acc32[a] = 0.0f;
     }
@@ -174,7 +184,20 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
         RPF_STAMP(clk, 12);                      // last fetch
         if constexpr (!(ABL & 2)) phase_last<G>(x);
         RPF_STAMP(clk, 13);                      // last butterfly
-        if constexpr (ACCB > 0) {
+        if constexpr (ACCP) {
+            if (active) {
+#pragma unroll
+                for (int a = 0; a < P; ++a)
+                    asm("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(acc32p[a]) : "v"(x[a]));
+            }
+            if ((it % ACCN) == ACCN - 1) {
+#pragma unroll
+                for (int a = 0; a < P; ++a) {
+                    acc[a] += static_cast<double>(acc32p[a].x) + static_cast<double>(acc32p[a].y);
+                    acc32p[a] = cf{0.0f, 0.0f};
+                }
+            }
+        } else if constexpr (ACCB > 0) {
             if (active) {
 #pragma unroll
                 for (int a = 0; a < P; ++a)
@@ -197,7 +220,10 @@ __global__ __launch_bounds__(WG, OCC) void fft_accum_kernel(const uint8_t* __res
     }
     clk.publish(lane);
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (clamped) prefetches
-    if constexpr (ACCB > 0) {
+    if constexpr (ACCP) {
+#pragma unroll
+        for (int a = 0; a < P; ++a) acc[a] += static_cast<double>(acc32p[a].x) + static_cast<double>(acc32p[a].y);
+    } else if constexpr (ACCB > 0) {
 #pragma unroll
         for (int a = 0; a < P; ++a) acc[a] += static_cast<double>(acc32[a]);
     }
@@ -945,6 +971,8 @@ const Variant kVariants[] = {
     make_variant<4096, 16, 3, 2, false, 0, false, 2, 0, true>(9),               // 256 threads, 3 (windowed: 2) workgroups per CU
     make_variant<4096, 16, 2, 2, false, 0, false, 2, 0, true>(10),              // 256 threads, 2 workgroups per CU
     make_variant<4096, 16, 2, 2, false, 8, false, 2, 0, true, 512>(22),  // 512 threads, float32 batch accumulate, f64 partials
+    make_variant<4096, 16, 2, 2, false, 108, false, 2, 0, true, 512>(23),  // round 6: PACKED float32 pre-accumulate over 8 frames
+    make_variant<4096, 16, 2, 2, false, 116, false, 2, 0, true, 512>(24),  // ... over 16 frames
     make_variant<4096, 16, 2, 2, true, 0, false, 1, 0, true, 512>(26),   // 512 threads, double-buffered slab (no top barrier), raw ring 1
     // round 3: deeper raw rings for HBM-resident input (one workgroup per CU leaves the LDS for it),
     // pass-2 twiddles back in registers (the 512-thread form has the registers)

@@ -214,14 +214,20 @@ def emul_bluestein(N, stream, nframes, window=None):
 def truth_f64(N, stream, repeats, window=None):
     """numpy complex128 evaluation of datastore.cxx:66-89 (exact unpack, float32
     window product, float64 FFT and accumulate)."""
-    x = np.asarray(stream[: 2 * N * repeats]).astype(np.float32).reshape(repeats, N, 2) - np.float32(127.0)
     sign = (1 - 2 * (np.arange(N) % 2)).astype(np.float32)
-    x = x * sign[None, :, None]
-    if window is not None:
-        x = x * np.asarray(window, dtype=np.float32)[None, :, None]
-    z = x[..., 0].astype(np.float64) + 1j * x[..., 1].astype(np.float64)
-    spec = np.fft.fft(z, axis=1)
-    return (spec.real ** 2 + spec.imag ** 2).sum(axis=0)
+    w = None if window is None else np.asarray(window, dtype=np.float32)
+    total = np.zeros(N)
+    chunk = max(1, (1 << 24) // N)                  # <= 16 M samples (0.8 GB of complex128 work arrays) at a time
+    for f0 in range(0, repeats, chunk):
+        f1 = min(repeats, f0 + chunk)
+        x = np.asarray(stream[2 * N * f0: 2 * N * f1]).astype(np.float32).reshape(f1 - f0, N, 2) - np.float32(127.0)
+        x = x * sign[None, :, None]
+        if w is not None:
+            x = x * w[None, :, None]
+        z = x[..., 0].astype(np.float64) + 1j * x[..., 1].astype(np.float64)
+        spec = np.fft.fft(z, axis=1)
+        total += (spec.real ** 2 + spec.imag ** 2).sum(axis=0)
+    return total
 
 
 def max_rel(a, b):

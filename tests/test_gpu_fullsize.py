@@ -33,7 +33,7 @@ def oracle_all_cores(n, stream, repeats, window=None):
 
 def record(name, **values):
     """Measured errors of the full-size runs, kept for DESIGN.md: into the file $RPF_PARITY_RECORD names
-    (tools/gpu_final_check.sh sets it); without it nothing is written -- running the tests leaves the tree alone."""
+    (tools/gpu_r06.sh sets it); without it nothing is written -- running the tests leaves the tree alone."""
     path = os.environ.get("RPF_PARITY_RECORD")
     if not path:
         return

@@ -1,19 +1,23 @@
 """The fused four-step kernel (the default of 65536 ... 262144 bins, config C4) is a persistent launch whose 256
 workgroups must be co-resident; when they are not -- another process holding a CU -- the launch gives up.  The
 reference's worker has no failure path (/root/reference/src/datastore.cxx:48-96): neither may this give-up lose an
-acquisition.  Driven here with rpf_debug_fused_fault (include/rpf_engine.h): mode 1 makes a launch give up at once
+acquisition.  Driven here with rpf_debug_fused_fault (csrc/rpf_engine_testing.h: a test hook, not part of the ABI): mode 1 makes a launch give up at once
 (a 33rd workgroup on XCD 0), mode 2 is the real thing (a squatter kernel holds one CU until the spins run out).
 Run on the GPU box with  pytest -m gpu."""
 import numpy as np
 import pytest
 
 import rtl_power_fftw_amd as rpf
-from helpers import max_rel, oracle_accumulate
-from parity_bars import FUSED_VS_TWO_KERNEL, PARITY
+from helpers import max_rel, truth_f64
+from parity_bars import FUSED_VS_TWO_KERNEL, TRUTH_BAR
 
 pytestmark = pytest.mark.gpu
 
 N = 262144                      # config C4's size; a staging slot holds 64 frames (32 MB)
+# These tests are about the protocol -- nothing lost, nothing NaN, the right path afterwards -- on tone streams at C4's
+# size, where the asserted accuracy is the distance from float64 TRUTH (parity_bars.py section 4: the CPU path is itself
+# ~1.5e-6 off beside the lines there).  `want` below is that truth.
+BAR = TRUTH_BAR[N]
 
 
 @pytest.fixture(scope="module")
@@ -38,8 +42,8 @@ def c4_stream():
         assert not plain.fused_status()["active"]
         two_kernel, done = plain.accumulate(stream, R)
     assert done == R
-    want, _ = oracle_accumulate(N, stream, R, None, 32)
-    assert max_rel(two_kernel, want) < PARITY
+    want = truth_f64(N, stream, R)
+    assert max_rel(two_kernel, want) < BAR
     return R, stream, two_kernel, want
 
 
@@ -51,7 +55,7 @@ def test_fused_abort_falls_back_and_recovers(c4_stream):
     with rpf.Datastore(rpf.Params(N=N, repeats=R)) as ds:
         needs_fused(ds)
         ok, done = ds.accumulate(stream, R)                     # first: the fused kernel as shipped
-        assert done == R and max_rel(ok, want) < PARITY
+        assert done == R and max_rel(ok, want) < BAR
         assert ds.fused_status() == {"active": True, "gave_up": 0, "recovered": 0}
         ds.debug_fused_fault(1, skip=0, count=-1)
         got, done = ds.accumulate(stream, R)                    # rc != 0 would raise
@@ -68,7 +72,7 @@ def test_fused_abort_falls_back_and_recovers(c4_stream):
 def test_one_launch_gives_up_in_any_slot(c4_stream, skip):
     """ONE launch of the acquisition gives up -- the first, a middle one (the advisor's case: the next launch clears
     the kernel's own abort flag), the last: the slot's bytes are run again on the two-kernel path, the other slots'
-    fused results stay.  Equal to the oracle; and to the all-fused / all-two-kernel spectra within what one slot of
+    fused results stay.  Within the bar of float64 truth; and to the all-fused / all-two-kernel spectra within what one slot of
     the other kernel changes."""
     R, stream, two_kernel, want = c4_stream
     with rpf.Datastore(rpf.Params(N=N, repeats=R)) as ds:
@@ -78,7 +82,7 @@ def test_one_launch_gives_up_in_any_slot(c4_stream, skip):
         st = ds.fused_status()
     assert done == R and np.all(np.isfinite(got))
     assert st["gave_up"] == 1 and st["recovered"] == 1 and not st["active"]
-    assert max_rel(got, want) < PARITY
+    assert max_rel(got, want) < BAR
     assert max_rel(got, two_kernel) < FUSED_VS_TWO_KERNEL
 
 
@@ -87,7 +91,7 @@ def test_buffer_protocol_with_straddling_frames_survives_a_give_up():
     with the second launch giving up: the re-run slot starts with a carried partial frame."""
     R = 150
     stream = rpf.synth.noise_tones_iq(44, N * R + 3000)
-    want, wdone = oracle_accumulate(N, stream, R, None, 32)
+    want, wdone = truth_f64(N, stream, R), R
     with rpf.Datastore(rpf.Params(N=N, repeats=R, buf_length=1638400, buffers=5)) as ds:
         needs_fused(ds)
         ds.debug_fused_fault(1, skip=1, count=1)
@@ -103,7 +107,7 @@ def test_buffer_protocol_with_straddling_frames_survives_a_give_up():
         st = ds.fused_status()
         assert done == wdone == R
         assert st["gave_up"] == 1 and st["recovered"] == 1
-        assert max_rel(ds.pwr, want) < PARITY
+        assert max_rel(ds.pwr, want) < BAR
 
 
 def test_device_path_give_up_is_loud_and_the_engine_moves_on(torch_dev):
@@ -113,7 +117,7 @@ def test_device_path_give_up_is_loud_and_the_engine_moves_on(torch_dev):
     import torch
     R = 40
     stream = rpf.synth.noise_tones_iq(5, N * R)
-    want, _ = oracle_accumulate(N, stream, R, None, 32)
+    want = truth_f64(N, stream, R)
     d_in = torch.from_numpy(stream).to(torch_dev)
     s = torch.cuda.current_stream().cuda_stream
     with rpf.Datastore(rpf.Params(N=N, repeats=R)) as ds:
@@ -128,7 +132,7 @@ def test_device_path_give_up_is_loud_and_the_engine_moves_on(torch_dev):
         assert ds.accumulate_device(d_in.data_ptr(), stream.size, R, d_out.data_ptr(), s) == R
         torch.cuda.synchronize()
         got = d_out.cpu().numpy()
-        assert np.all(np.isfinite(got)) and max_rel(got, want) < PARITY
+        assert np.all(np.isfinite(got)) and max_rel(got, want) < BAR
         assert ds.fused_status() == st
 
 
@@ -144,7 +148,7 @@ def test_a_cu_held_by_another_kernel_is_survived(c4_stream):
         st = ds.fused_status()
     assert done == R and np.all(np.isfinite(got))
     assert st["gave_up"] >= 1 and st["recovered"] == st["gave_up"] and not st["active"]
-    assert max_rel(got, want) < PARITY
+    assert max_rel(got, want) < BAR
 
 
 def test_fused_is_what_the_four_step_sizes_run_by_default():

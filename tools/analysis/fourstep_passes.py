@@ -1,0 +1,116 @@
+"""Which pass of the four-step transform carries the error that does not average down?  (CPU only, numpy.)
+
+A float32 emulation of X[k1 + N1 k2] = sum_n2 W_N2^{n2 k2} ( W_N^{n2 k1} sum_n1 x[N2 n1 + n2] W_N1^{n1 k1} ) -- decimation in
+frequency, radix-8 passes like rpf_fourstep.hip's, every pass's outputs rounded to float32 -- on 64 frames of the noise +
+tones stream, with any pass run in double instead, and with the twiddle TABLES either rounded to float32 (what the kernels
+read) or exact.  It is not bit-identical to the kernels (the butterflies here are direct sums); it answers WHICH rounding
+matters.  Round 6's finding (profiles/r06_fourstep_wide.txt): at 131072 bins the worst bin is a weak deterministic line
+(bin 2N/16) that shares its last two row butterflies with a strong line; arithmetic in double alone leaves 1.3e-6 there,
+because the float32 REPRESENTATION error of the pass-2 twiddles (1.7e-8 on 1/sqrt(2)) leaks the strong line into the weak
+one identically in every frame; the last two row passes in double WITH exact twiddles leave 2.3e-7, and exact twiddles
+alone -- the pass's butterflies still float32, each product x (hi + lo) rounded once -- 2.7 - 5.3e-7 (the shipped form).
+
+Usage: python tools/analysis/fourstep_passes.py N [seed]     (N = 65536, 131072, 262144; default seed: the pickers' 300 + N % 89)
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+import rtl_power_fftw_amd as rpf
+from helpers import truth_f64
+
+
+def dft_mat(R, dtype):
+    k = np.arange(R)
+    return np.exp(-2j * np.pi * np.outer(k, k) / R).astype(dtype)
+
+
+def fft_dif(x, radices, wide=(), exact_tw=(), comp_tw=()):
+    """x: [B, L] complex64 -> natural-order spectrum [B, L] complex64.  Pass i (radix radices[i]) runs in complex128 when
+    i is in `wide` (inputs converted, outputs rounded back to complex64); its output twiddles are the float32-rounded
+    table's values unless i is in `exact_tw` (a wide pass with double twiddles) or in `comp_tw` (a float32 pass whose
+    products are x (hi + lo): evaluated here as the float32 butterfly output times the exact twiddle, rounded once)."""
+    B, L = x.shape
+    cur = x.reshape(B, 1, L)
+    for i, R in enumerate(radices):
+        G, Ls = cur.shape[1], cur.shape[2]
+        M = Ls // R
+        dt = np.complex128 if i in wide else np.complex64
+        y = np.einsum("ra,bgam->bgrm", dft_mat(R, dt), cur.reshape(B, G, R, M).astype(dt))
+        if M > 1:
+            tw = np.exp(-2j * np.pi * np.outer(np.arange(R), np.arange(M)) / Ls)
+            if i in comp_tw:      # float32 butterfly, product with the exact twiddle rounded once (a hi + lo float pair)
+                y = (y.astype(np.complex64).astype(np.complex128) * tw[None, None]).astype(np.complex64)
+            else:
+                tw = tw.astype(dt) if i in exact_tw else tw.astype(np.complex64).astype(dt)
+                y = y * tw[None, None]
+        cur = y.astype(np.complex64).reshape(B, G * R, M)
+    out = cur.reshape(B, L)
+    # group index = digits (r1, r2, ...) most significant first; bin = r1 + R1 r2 + R1 R2 r3 ...
+    rem = np.arange(L)
+    k = np.zeros(L, dtype=np.int64)
+    weight = 1
+    for j, R in enumerate(radices):
+        span = int(np.prod(radices[j + 1:])) if j + 1 < len(radices) else 1
+        k += (rem // span) * weight
+        rem = rem % span
+        weight *= R
+    res = np.empty_like(out)
+    res[:, k] = out
+    return res
+
+
+def fourstep(x, N1, N2, rad1, rad2, wide_col=(), wide_row=(), exact_row=(), exact_col=(), step_exact=False, comp_row=()):
+    B = x.shape[0]
+    cols = np.ascontiguousarray(x.reshape(B, N1, N2).transpose(0, 2, 1)).reshape(B * N2, N1)
+    A = fft_dif(cols, rad1, wide_col, exact_col).reshape(B, N2, N1)
+    tw = np.exp(-2j * np.pi * np.outer(np.arange(N2), np.arange(N1)) / (N1 * N2))
+    A = (A.astype(np.complex128) * tw[None]).astype(np.complex64) if step_exact else A * tw.astype(np.complex64)[None]
+    rows = np.ascontiguousarray(A.transpose(0, 2, 1)).reshape(B * N1, N2)
+    X = fft_dif(rows, rad2, wide_row, exact_row, comp_row).reshape(B, N1, N2)
+    return np.ascontiguousarray(X.transpose(0, 2, 1)).reshape(B, N1 * N2)
+
+
+def main():
+    N = int(sys.argv[1])
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 300 + N % 89
+    N1, N2, r1, r2 = {65536: (256, 256, (8, 8, 4), (8, 8, 4)), 131072: (512, 256, (8, 8, 8), (8, 8, 4)),
+                      262144: (512, 512, (8, 8, 8), (8, 8, 8))}[N]
+    R = 64
+    stream = rpf.synth.noise_tones_iq(seed, N * R)
+    truth = truth_f64(N, stream, R)
+    x = stream.astype(np.float32).reshape(R, N, 2) - np.float32(127)
+    x = x * (1 - 2 * (np.arange(N) % 2)).astype(np.float32)[None, :, None]
+    x = (x[..., 0] + 1j * x[..., 1]).astype(np.complex64)
+    print("N = %d = %d x %d, seed %d, %d frames, rectangular; max over bins of |pwr - truth| / truth" % (N, N1, N2, seed, R))
+
+    def run(name, **kw):
+        t0 = time.time()
+        acc = np.zeros(N)
+        for f0 in range(0, R, 8):
+            X = fourstep(x[f0:f0 + 8], N1, N2, r1, r2, **kw).astype(np.complex128)
+            acc += (X.real ** 2 + X.imag ** 2).sum(0)
+        rel = np.abs(acc - truth) / truth
+        k = int(np.argmax(rel))
+        print("%-62s %.2e at bin %6d (k1 = %3d, k2 = %3d); 99.9 %% of bins below %.2e  [%.0f s]" % (
+            name, rel.max(), k, k % N1, k // N1, np.quantile(rel, 0.999), time.time() - t0), flush=True)
+
+    run("every pass float32, float32 twiddle tables (rounds 1 - 5)")
+    run("last row pass in double", wide_row=(2,))
+    run("last two row passes in double, float32 tables", wide_row=(1, 2))
+    run("every pass of both transforms in double, float32 tables", wide_row=(0, 1, 2), wide_col=(0, 1, 2), step_exact=True)
+    run("every pass float32, EXACT tables", exact_row=(0, 1), exact_col=(0, 1), step_exact=True)
+    run("last row pass in double, pass-2 row twiddles exact", wide_row=(2,), exact_row=(1,))
+    run("last row pass in double, pass-2 float32 butterfly x (hi + lo) twiddle (shipped from 131072)", wide_row=(2,), comp_row=(1,))
+    run("last two row passes in double, pass-2 row twiddles exact (RPF_FOURSTEP_WIDE2=2)", wide_row=(1, 2), exact_row=(1,))
+    run("every pass in double, EXACT tables (float32 storage only)", wide_row=(0, 1, 2), wide_col=(0, 1, 2), exact_row=(0, 1),
+        exact_col=(0, 1), step_exact=True)
+
+
+if __name__ == "__main__":
+    main()

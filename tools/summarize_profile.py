@@ -130,6 +130,13 @@ if "FETCH_SIZE" in ks and "WRITE_SIZE" in ks:
     traffic["fft_accum_c5_fetch_bytes_per_launch"] = ks["FETCH_SIZE"] * 1024.0 * 2.0
     traffic["fft_accum_c5_write_bytes_per_launch"] = ks["WRITE_SIZE"] * 1024.0
     traffic["fft_accum_c5_hbm_bytes_per_launch"] = ks["FETCH_SIZE"] * 1024.0 * 2.0 + ks["WRITE_SIZE"] * 1024.0
+    # the frames ONE launch of that capture covered (round 6: a launch spans several consecutive scans): bench.py scales
+    # the replayed traffic to the frames of ITS launch
+    try:
+        c5_line = json.load(open(os.path.join(src, "c5_bench.json")))
+        traffic["fft_accum_c5_frames_per_launch"] = c5_line["roofline"]["frames_per_launch"]
+    except Exception:
+        traffic["fft_accum_c5_frames_per_launch"] = 40000
 
 # C4: one acquisition = ONE launch of the column kernel and one of the row kernel (round 3: 2 GB of intermediate;
 # rounds 1-2: 8 batches of 128 frames)
