@@ -87,13 +87,13 @@ __device__ __forceinline__ void group_fft(int t, cf* x, const cf (&tw)[G::NPASS 
 // a's bin as after phase_last.  WIDE: that pass in double, like the split forms' (dft_small_wide.h) -- the pass in which a
 // line's energy has collected in one butterfly, so that every float32 rounding inside it lands on the weak bins beside
 // the line.  Shipped from kFourstepWideFrom bins up (round 6): measured (profiles/r05_fourstep_wide.txt,
-// r06_fourstep_wide.txt) the GPU then sits 0.6 - 0.8e-6 from float64 truth at 131072 / 262144 bins instead of 1.3 - 2.5e-6,
-// for 2 % of C4's rate.  It also moves the GPU AWAY from oracle/rpf_oracle.c on the line bins (C4: 4.8e-7 -> 1.6e-6): at these
+// r06_fourstep_wide.txt) the GPU then sits 0.4 - 1.4e-6 from float64 truth at 131072 / 262144 bins instead of 1.3 - 2.5e-6,
+// for 2 % of C4's rate (and 2.1 - 7.1e-7 with the exact twiddles below).  It also moves the GPU AWAY from oracle/rpf_oracle.c on the line bins (C4: 4.8e-7 -> 1.6e-6): at these
 // power-of-two lengths the oracle's radix-4 / 2 float32 butterflies and the float32 pass make the same roundings beside a line
 // and agree with each other far better than either agrees with the truth.  The reference's arithmetic is FFTW's
 // (/root/reference/src/datastore.cxx:82), whose codelets share neither's roundings, and |gpu - FFTW| <= |gpu - truth| +
 // |FFTW - truth|: the distance from the truth is the objective, the agreement with the (unpinned) oracle was an artefact.
-// -DRPF_FOURSTEP_WIDE=0 (`make fsfloat`, A/B only) builds every size on the float32 pass, =1 every size on the wide one.
+// -DRPF_FOURSTEP_WIDE=0 (`make f32pass`, A/B only) builds every size on the float32 pass, =1 every size on the wide one.
 #ifndef RPF_FOURSTEP_WIDE
 #define RPF_FOURSTEP_WIDE -1
 #endif

@@ -26,7 +26,8 @@ on these seeds.  The sizes of parity_bars.TRUTH_BAR (98304 bins and up on these 
 History.  Round 4: ten split-form sizes failed on a / b and left the table.  Round 5: parity_passes found where the
 split / paired forms lose their accuracy (the LAST pass, beside a strong line), the forms of 40000 bins and more run
 that pass in double, and the ten sizes came back on the plans they had.  Round 6: the four-step kernels run the row
-transform's last pass in double from 131072 bins up (rpf_fourstep.hip, fourstep_is_wide).
+transform's last pass in double (rpf_fourstep.hip, fourstep_is_wide) and, from 131072 bins up, the pass before it with
+twiddles exact to double precision (fourstep_wide2).
 
 The errors are written to the file $RPF_PARITY_RECORD names (tools/gpu_r06.sh sets it ->
 profiles/rNN_fullsize_errors.json), else to pytest's tmp_path: running the tests has no side effect on the tree."""
