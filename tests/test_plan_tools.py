@@ -99,3 +99,17 @@ def test_lds_bank_model_of_the_fused_kernel():
         assert m.staging(N, sw, N, wide=True) == (32, 32, 16, 16)       # conflict-free -- and measured worth nothing
     assert [m.raw_rows(b, False)[0] for b in (32, 64, 128)] == [16, 32, 64]
     assert [m.raw_rows(b, True)[0] for b in (32, 64, 128)] == [8, 8, 8]
+
+
+def test_why_the_four_step_kernels_multiply_by_exact_twiddles():
+    """tools/analysis/fourstep_passes.py, the float32 emulation rpf_fourstep.hip's round-6 passes were designed on, at
+    131072 bins on the pickers' stream (64 frames, CPU, ~10 s): with the row transform's last pass in double the worst
+    bin is still ~1e-6 from float64 truth; making nothing but the pass-before-the-last's twiddles exact (butterflies
+    float32: the shipped form) halves that; the GPU's own numbers are profiles/r06_fourstep_wide.txt."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "analysis"))
+    import fourstep_passes as fp
+    case = fp.Case(131072, R=64)
+    err = {name: case.error(**kw)[0] for name, kw in fp.FORMS.items() if name != "float32"}
+    assert err["last_pass_double"] > 8e-7, err
+    assert err["exact_twiddles"] < 0.6 * err["last_pass_double"], err
+    assert err["last_two_passes_double"] <= err["exact_twiddles"] * 1.05, err

@@ -76,29 +76,54 @@ def fourstep(x, N1, N2, rad1, rad2, wide_col=(), wide_row=(), exact_row=(), exac
     return np.ascontiguousarray(X.transpose(0, 2, 1)).reshape(B, N1 * N2)
 
 
+SPLITS = {65536: (256, 256, (8, 8, 4), (8, 8, 4)), 131072: (512, 256, (8, 8, 8), (8, 8, 4)),
+          262144: (512, 512, (8, 8, 8), (8, 8, 8))}
+
+
+class Case:
+    """R frames of the noise + tones stream of `seed` at N bins, rectangular: the unpacked samples and the float64 truth."""
+
+    def __init__(self, N, seed=None, R=64):
+        self.N, self.R = N, R
+        self.seed = 300 + N % 89 if seed is None else seed      # default: the stream the plan pickers scored on
+        stream = rpf.synth.noise_tones_iq(self.seed, N * R)
+        self.truth = truth_f64(N, stream, R)
+        x = stream.astype(np.float32).reshape(R, N, 2) - np.float32(127)
+        x = x * (1 - 2 * (np.arange(N) % 2)).astype(np.float32)[None, :, None]
+        self.x = (x[..., 0] + 1j * x[..., 1]).astype(np.complex64)
+
+    def error(self, **kw):
+        """(max over bins of |pwr - truth| / truth, that bin, the 99.9 % quantile) of the emulated transform `kw`"""
+        N1, N2, r1, r2 = SPLITS[self.N]
+        acc = np.zeros(self.N)
+        for f0 in range(0, self.R, 8):
+            X = fourstep(self.x[f0:f0 + 8], N1, N2, r1, r2, **kw).astype(np.complex128)
+            acc += (X.real ** 2 + X.imag ** 2).sum(0)
+        rel = np.abs(acc - self.truth) / self.truth
+        return float(rel.max()), int(np.argmax(rel)), float(np.quantile(rel, 0.999))
+
+
+# the forms rpf_fourstep.hip can be built in (RPF_FOURSTEP_WIDE / RPF_FOURSTEP_WIDE2), as arguments of fourstep()
+FORMS = {
+    "float32": dict(),
+    "last_pass_double": dict(wide_row=(2,)),
+    "exact_twiddles": dict(wide_row=(2,), comp_row=(1,)),                 # shipped from 131072 bins up
+    "last_two_passes_double": dict(wide_row=(1, 2), exact_row=(1,)),
+}
+
+
 def main():
     N = int(sys.argv[1])
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 300 + N % 89
-    N1, N2, r1, r2 = {65536: (256, 256, (8, 8, 4), (8, 8, 4)), 131072: (512, 256, (8, 8, 8), (8, 8, 4)),
-                      262144: (512, 512, (8, 8, 8), (8, 8, 8))}[N]
-    R = 64
-    stream = rpf.synth.noise_tones_iq(seed, N * R)
-    truth = truth_f64(N, stream, R)
-    x = stream.astype(np.float32).reshape(R, N, 2) - np.float32(127)
-    x = x * (1 - 2 * (np.arange(N) % 2)).astype(np.float32)[None, :, None]
-    x = (x[..., 0] + 1j * x[..., 1]).astype(np.complex64)
-    print("N = %d = %d x %d, seed %d, %d frames, rectangular; max over bins of |pwr - truth| / truth" % (N, N1, N2, seed, R))
+    case = Case(N, int(sys.argv[2]) if len(sys.argv) > 2 else None)
+    N1 = SPLITS[N][0]
+    print("N = %d = %d x %d, seed %d, %d frames, rectangular; max over bins of |pwr - truth| / truth" % (
+        N, N1, SPLITS[N][1], case.seed, case.R))
 
     def run(name, **kw):
         t0 = time.time()
-        acc = np.zeros(N)
-        for f0 in range(0, R, 8):
-            X = fourstep(x[f0:f0 + 8], N1, N2, r1, r2, **kw).astype(np.complex128)
-            acc += (X.real ** 2 + X.imag ** 2).sum(0)
-        rel = np.abs(acc - truth) / truth
-        k = int(np.argmax(rel))
+        worst, k, q = case.error(**kw)
         print("%-62s %.2e at bin %6d (k1 = %3d, k2 = %3d); 99.9 %% of bins below %.2e  [%.0f s]" % (
-            name, rel.max(), k, k % N1, k // N1, np.quantile(rel, 0.999), time.time() - t0), flush=True)
+            name, worst, k, k % N1, k // N1, q, time.time() - t0), flush=True)
 
     run("every pass float32, float32 twiddle tables (rounds 1 - 5)")
     run("last row pass in double", wide_row=(2,))
