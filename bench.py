@@ -139,7 +139,7 @@ def cpu_baseline(N, R, stream, pwr_gpu, window=None):
         "gpu_vs_cpu_max_rel_err": rel,
     }
     if rel >= 1e-6:
-        # C4's stream: the 16 bins of the deterministic lines, where the CPU path's float32 last pass is itself 1.59e-6 from
+        # C4's stream: a bin of the 16 deterministic lines, where the CPU path's float32 last pass is itself 1.59e-6 from
         # float64 truth and the GPU (last pass in double, exact twiddles before it) 1.3e-7 -- tests/parity_bars.py section 4,
         # profiles/r06_fullsize_errors.json "c4"; every other bin is reported beside them
         err = np.abs(pwr_gpu - pwr) / pwr
