@@ -128,9 +128,11 @@ __device__ __forceinline__ void last_pass_accumulate(cf* x, double* acc)
 // twiddle 1.  Three forms, RPF_FOURSTEP_WIDE2 =
 //   1 (shipped)  the pass's butterflies stay float32; each product is x (hi + lo), hi the float32 table's value and
 //                lo = float(exact - hi), read as one 16-byte (hi, lo) pair from a 0.4 - 0.9 KB LDS table: two more packed
-//                instructions per product, 14 per thread and transform, no more LDS instructions than before.  Emulated 2.3 - 5.3e-7 from the truth at 65536 ... 262144 bins.
-//   2 (A/B)      the whole pass in double with double twiddles: emulated 2.0 - 3.0e-7, measured 35 % of C4's rate.
-//   0 (A/B)      the last pass alone in double.
+//                instructions per product, 14 per thread and transform, no more LDS instructions than before.
+//                Emulated 2.3 - 5.3e-7 from the truth at 65536 ... 262144 bins; measured 2.1 - 7.1e-7 at 131072 / 262144
+//                on six streams x two windows, - 2.1 % on C4 beyond the double last pass.
+//   2 (A/B)      the whole pass in double with double twiddles: emulated 2.0 - 3.0e-7, measured 1.9 - 6.8e-7, - 5.5 % on C4.
+//   0 (A/B)      the last pass alone in double: up to 1.42e-6 at 131072 bins.
 #ifndef RPF_FOURSTEP_WIDE2
 #define RPF_FOURSTEP_WIDE2 1
 #endif
@@ -154,10 +156,10 @@ struct WideTwiddleTable {
 };
 template <int L>
 __device__ constexpr WideTwiddleTable<L> kWideTwiddles{};
-// The kernels read them from LDS (filled once per launch): form 2 as 16-byte doubles indexed by the exponent -- fetched
-// from global memory per transform they cost the fused kernel 28 % (14 scattered 8-byte loads per lane and transform in
-// a role whose memory queue is the tile loads'); form 1 as the float32 remainders, one row of P - 1 per m = t mod L_J,
-// laid out like fill_twlds lays out the table's own values.
+// The kernels read them from LDS (filled once per launch; from global memory per transform they cost the fused kernel
+// 28 %: scattered loads in a role whose memory queue is the tile loads'): form 2 as 16-byte doubles indexed by the
+// exponent; form 1 as (hi, lo) float pairs, one row of P - 1 per m = t mod L_J, laid out like fill_twlds lays out the
+// table's own values.
 constexpr int kWideTabBytes = 64 * (int)sizeof(cd) + 16;      // L <= 64 entries + room to align to 16 bytes
 template <class G>
 constexpr bool fourstep_has_wide_table(int n) { return fourstep_wide2<G>(n) != 0; }
