@@ -51,6 +51,9 @@ constexpr int kWG = 1024, kWaves = kWG / 64;
 constexpr int kColTile = 64;          // columns per K2a tile (128 raw bytes per row)
 constexpr int kRowDwords = 33;        // 32 data dwords + 1 pad per staged raw row
 constexpr size_t kScratchBytes = static_cast<size_t>(2048) << 20;      // of intermediate per launch pair
+// LDS set aside behind the rows kernels' slabs for the exact twiddles of the pass before the last (fourstep_wide2 below):
+// up to 64 entries of 16 bytes + room to align the table to 16 bytes
+constexpr int kWideTabBytes = 64 * 16 + 16;
 
 // Everything that depends on the factorisation N = N1 * N2.
 template <int N1_, int N2_>
@@ -67,7 +70,7 @@ struct Split {
     static constexpr int SLAB_A = SUBA * GA::LDS_CPX;                   // complex per wave
     static constexpr int SLAB_B = SUBB * GB::LDS_CPX;
     static constexpr int COLS_LDS = N1 * kRowDwords * 4 + kWaves * SLAB_A * (int)sizeof(cf);
-    static constexpr int ROWS_LDS = N2 * ROW_PITCH * (int)sizeof(cf) + kWaves * SLAB_B * (int)sizeof(cf) + 1040;   // + kWideTabBytes
+    static constexpr int ROWS_LDS = N2 * ROW_PITCH * (int)sizeof(cf) + kWaves * SLAB_B * (int)sizeof(cf) + kWideTabBytes;
     static constexpr int BATCH = (int)(kScratchBytes / (sizeof(cf) * (size_t)N));   // frames per launch pair
     static constexpr int GROUPS = (256 / ROW_TILES) < BATCH ? (256 / ROW_TILES) : BATCH;   // frame groups
     static_assert(GA::T <= 64 && GB::T <= 64 && COLS_PER_WAVE % SUBA == 0, "");
@@ -160,7 +163,7 @@ __device__ constexpr WideTwiddleTable<L> kWideTwiddles{};
 // 28 %: scattered loads in a role whose memory queue is the tile loads'): form 2 as 16-byte doubles indexed by the
 // exponent; form 1 as (hi, lo) float pairs, one row of P - 1 per m = t mod L_J, laid out like fill_twlds lays out the
 // table's own values.
-constexpr int kWideTabBytes = 64 * (int)sizeof(cd) + 16;      // L <= 64 entries + room to align to 16 bytes
+static_assert(kWideTabBytes == 64 * (int)sizeof(cd) + 16, "L <= 64 entries + room to align to 16 bytes");
 template <class G>
 constexpr bool fourstep_has_wide_table(int n) { return fourstep_wide2<G>(n) != 0; }
 // (the offset from the start of the LDS allocation is rounded up, not the pointer's integer value: a pointer that has been
