@@ -30,18 +30,53 @@ def dft_mat(R, dtype):
     return np.exp(-2j * np.pi * np.outer(k, k) / R).astype(dtype)
 
 
-def fft_dif(x, radices, wide=(), exact_tw=(), comp_tw=()):
+def butterfly8_float32(x, exact_const):
+    """x[..., 8] complex64 -> the 8-point DFT over the last axis in float32 arithmetic, stage by stage like Dft<8> of
+    dft_small.h (radix-2 stage, the W8 products, two radix-4 butterflies).  The two products by (1 -+ i)/sqrt(2) use the
+    float32 constant, or (exact_const) the exact one with ONE rounding of each product -- what a (hi + lo) constant gives."""
+    f32 = np.float32
+    v = [x[..., i].astype(np.complex64) for i in range(8)]
+    a = [v[i] + v[i + 4] for i in range(4)]
+    b = [v[i] - v[i + 4] for i in range(4)]
+    c = 1 / np.sqrt(2.0) if exact_const else f32(1 / np.sqrt(2.0))
+
+    def scaled(re, im):
+        if exact_const:
+            return ((re.astype(np.float64) * c).astype(f32) + 1j * (im.astype(np.float64) * c).astype(f32)).astype(np.complex64)
+        return ((re * c).astype(f32) + 1j * (im * c).astype(f32)).astype(np.complex64)
+
+    def minus_i(z):
+        return (z.imag - 1j * z.real).astype(np.complex64)
+    b = [b[0], scaled((b[1].real + b[1].imag).astype(f32), (b[1].imag - b[1].real).astype(f32)), minus_i(b[2]),
+         scaled((b[3].imag - b[3].real).astype(f32), (-(b[3].real + b[3].imag)).astype(f32))]
+
+    def radix4(u):
+        t0, t1, t2, t3 = u[0] + u[2], u[0] - u[2], u[1] + u[3], minus_i(u[1] - u[3])
+        return [(t0 + t2).astype(np.complex64), (t1 + t3).astype(np.complex64), (t0 - t2).astype(np.complex64),
+                (t1 - t3).astype(np.complex64)]
+    even, odd = radix4(a), radix4(b)
+    out = np.empty(v[0].shape + (8,), dtype=np.complex64)
+    for k in range(4):
+        out[..., 2 * k], out[..., 2 * k + 1] = even[k], odd[k]
+    return out
+
+
+def fft_dif(x, radices, wide=(), exact_tw=(), comp_tw=(), last8=None):
     """x: [B, L] complex64 -> natural-order spectrum [B, L] complex64.  Pass i (radix radices[i]) runs in complex128 when
     i is in `wide` (inputs converted, outputs rounded back to complex64); its output twiddles are the float32-rounded
     table's values unless i is in `exact_tw` (a wide pass with double twiddles) or in `comp_tw` (a float32 pass whose
-    products are x (hi + lo): evaluated here as the float32 butterfly output times the exact twiddle, rounded once)."""
+    products are x (hi + lo): evaluated here as the float32 butterfly output times the exact twiddle, rounded once).
+    last8 = "float32" / "exact_const": a last pass of radix 8 is butterfly8_float32 (explicit float32 steps) instead."""
     B, L = x.shape
     cur = x.reshape(B, 1, L)
     for i, R in enumerate(radices):
         G, Ls = cur.shape[1], cur.shape[2]
         M = Ls // R
         dt = np.complex128 if i in wide else np.complex64
-        y = np.einsum("ra,bgam->bgrm", dft_mat(R, dt), cur.reshape(B, G, R, M).astype(dt))
+        if last8 is not None and i == len(radices) - 1 and R == 8:
+            y = butterfly8_float32(cur.reshape(B, G, R, M).transpose(0, 1, 3, 2), last8 == "exact_const").transpose(0, 1, 3, 2)
+        else:
+            y = np.einsum("ra,bgam->bgrm", dft_mat(R, dt), cur.reshape(B, G, R, M).astype(dt))
         if M > 1:
             tw = np.exp(-2j * np.pi * np.outer(np.arange(R), np.arange(M)) / Ls)
             if i in comp_tw:      # float32 butterfly, product with the exact twiddle rounded once (a hi + lo float pair)
@@ -65,14 +100,15 @@ def fft_dif(x, radices, wide=(), exact_tw=(), comp_tw=()):
     return res
 
 
-def fourstep(x, N1, N2, rad1, rad2, wide_col=(), wide_row=(), exact_row=(), exact_col=(), step_exact=False, comp_row=()):
+def fourstep(x, N1, N2, rad1, rad2, wide_col=(), wide_row=(), exact_row=(), exact_col=(), step_exact=False, comp_row=(),
+             last8=None):
     B = x.shape[0]
     cols = np.ascontiguousarray(x.reshape(B, N1, N2).transpose(0, 2, 1)).reshape(B * N2, N1)
     A = fft_dif(cols, rad1, wide_col, exact_col).reshape(B, N2, N1)
     tw = np.exp(-2j * np.pi * np.outer(np.arange(N2), np.arange(N1)) / (N1 * N2))
     A = (A.astype(np.complex128) * tw[None]).astype(np.complex64) if step_exact else A * tw.astype(np.complex64)[None]
     rows = np.ascontiguousarray(A.transpose(0, 2, 1)).reshape(B * N1, N2)
-    X = fft_dif(rows, rad2, wide_row, exact_row, comp_row).reshape(B, N1, N2)
+    X = fft_dif(rows, rad2, wide_row, exact_row, comp_row, last8).reshape(B, N1, N2)
     return np.ascontiguousarray(X.transpose(0, 2, 1)).reshape(B, N1 * N2)
 
 
@@ -133,6 +169,11 @@ def main():
     run("last row pass in double, pass-2 row twiddles exact", wide_row=(2,), exact_row=(1,))
     run("last row pass in double, pass-2 float32 butterfly x (hi + lo) twiddle (shipped from 131072)", wide_row=(2,), comp_row=(1,))
     run("last two row passes in double, pass-2 row twiddles exact (RPF_FOURSTEP_WIDE2=2)", wide_row=(1, 2), exact_row=(1,))
+    if SPLITS[N][3][-1] == 8:
+        # what the double last pass buys when it is a radix-8 pass: mostly an exact 1/sqrt(2)
+        run("float32 last pass, explicit steps (= every pass float32)", last8="float32")
+        run("float32 last pass with an exact 1/sqrt(2), float32 tables", last8="exact_const")
+        run("float32 last pass with an exact 1/sqrt(2), pass-2 (hi + lo) twiddles", last8="exact_const", comp_row=(1,))
     run("every pass in double, EXACT tables (float32 storage only)", wide_row=(0, 1, 2), wide_col=(0, 1, 2), exact_row=(0, 1),
         exact_col=(0, 1), step_exact=True)
 
